@@ -1,0 +1,116 @@
+/* summertts_hip.h -- C ABI of libsummertts_hip.so, the MI355X (gfx950) acoustic + vocoder engine.
+ *
+ * This is the drop-in boundary for the hot path of huakunyang/SummerTTS: everything that
+ * SynthesizerTrn::infer does AFTER the text frontend has produced phoneme ids
+ * (/root/reference/src/models/SynthesizerTrn.cpp:357-400) and the model construction it depends on
+ * (SynthesizerTrn.cpp:91-163).  Plain pointers and sizes only -- no C++/torch types -- so the
+ * reference's C++ class (include/SynthesizerTrn.h in this repo keeps the reference's exact class
+ * surface) or any other host language binds to it directly.  See INTEGRATION.md for the binding a
+ * SummerTTS maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative STS_E* code; sts_last_error()
+ * returns a static, thread-local description.  Buffers returned through `**` out-parameters are
+ * malloc()'d and owned by the caller (free with sts_free == the reference's tts_free_data,
+ * /root/reference/src/utils/utils.cpp:34-37).  An engine is not re-entrant (neither is the
+ * reference instance); use one engine per host thread / per GPU.
+ */
+#ifndef SUMMERTTS_HIP_H_
+#define SUMMERTTS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sts_engine sts_engine;
+
+enum {
+    STS_OK = 0,
+    STS_EINVAL = -1,   /* bad argument (null pointer, phoneme id outside the vocabulary, n <= 0 ...) */
+    STS_EMODEL = -2,   /* the blob does not parse as a SummerTTS model */
+    STS_EDEVICE = -3,  /* HIP runtime failure (no gfx950 device, out of memory ...) */
+    STS_ESTATE = -4    /* call sequence error (e.g. asking for a tap that was not recorded) */
+};
+
+/* Replaces SynthesizerTrn::SynthesizerTrn(float* modelData, int32_t modelSize)
+ * (/root/reference/src/models/SynthesizerTrn.cpp:91-163): parses the float-stream blob (size in BYTES,
+ * as ttsLoadModel returns it), repacks and uploads the weights to HIP device `device`.  The blob is
+ * copied; the caller may free it afterwards (as test/main.cpp:144-145 does). */
+int sts_create(const float* blob, int64_t blob_bytes, int device, sts_engine** out);
+void sts_destroy(sts_engine* e);
+
+/* Replaces SynthesizerTrn::getSpeakerNum (SynthesizerTrn.cpp:79-89): 1 for single-speaker models. */
+int sts_speaker_num(const sts_engine* e);
+
+/* Model facts the host side needs (vocabulary size for id validation, samples per frame, ...). */
+typedef struct sts_model_info {
+    int32_t is_multi_speaker, lang_type, dur_pred_type, dec_type;
+    int32_t vocab, hidden, inter_channels, speaker_num, gin_channels;
+    int32_t samples_per_frame;      /* total upsampling factor */
+    int32_t sample_rate;            /* 16000 (/root/reference/test/main.cpp:13,16) */
+    int64_t blob_floats_consumed;   /* floats consumed by the acoustic sections (frontend sections follow) */
+} sts_model_info;
+int sts_get_info(const sts_engine* e, sts_model_info* info);
+
+/* Replaces the post-frontend part of SynthesizerTrn::infer (SynthesizerTrn.cpp:357-400) for one
+ * utterance: ids[n] -> int16 PCM.  Out-of-range sid -> 0 (SynthesizerTrn.cpp:366-369).
+ * *pcm_out is malloc()'d; *n_out = sample count. */
+int sts_infer_ids(sts_engine* e, const int32_t* ids, int32_t n, int32_t sid, float length_scale,
+                  int16_t** pcm_out, int32_t* n_out);
+
+/* Batched form (new capability; the reference processes exactly one utterance per call).  The B
+ * utterances are packed along time on the device and run through every kernel together.
+ * pcm_out[b] is malloc()'d per utterance. */
+int sts_infer_ids_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int32_t* n,
+                        const int32_t* sid, const float* length_scale, int16_t** pcm_out, int32_t* n_out);
+
+/* Same, but leaves the PCM on the device (packed back to back, utterance order) for a following
+ * RCCL gather; n_out[b] = samples of utterance b, *total_out = sum.  Copy out with
+ * sts_copy_pcm_device (device-to-device, asynchronous on the engine stream then synchronised). */
+int sts_run_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int32_t* n, const int32_t* sid,
+                  const float* length_scale, int32_t* n_out, int64_t* total_out);
+int sts_copy_pcm_device(sts_engine* e, void* device_dst, int64_t capacity_samples);
+int sts_copy_pcm_host(sts_engine* e, int16_t* host_dst, int64_t capacity_samples);
+
+/* Parity/diagnostic controls (test infrastructure hooks; defaults reproduce the reference):
+ *   forced durations: per-phoneme frame counts that override ceil(exp(logw)*lengthScale) for the NEXT
+ *   run only (the ceil is discontinuous, so waveform parity is checked with the
+ *   oracle's durations).  Packed for the whole batch (sum of n entries). */
+int sts_set_forced_durations(sts_engine* e, const int32_t* dur, int64_t count);
+/*   record intermediate tensors of the next run: "x_enc","m","logw","z_p","z","wave" */
+int sts_set_record_taps(sts_engine* e, int enable);
+/*   fetch a tap: malloc()'d copy, channel-major [channels][total_len] (== the reference's column-major
+ *   MatrixXf [time, channels]); for batches the utterances are packed along time. */
+int sts_get_tap(sts_engine* e, const char* name, float** data, int32_t* channels, int64_t* length);
+/*   durations of the last run, packed (sum of n entries) */
+int sts_get_durations(sts_engine* e, int32_t* dur, int64_t capacity);
+/*   conv dispatch: 0 = automatic, 1 = force the generic VALU kernel everywhere, 2.. = force MFMA tile (idx-2) */
+int sts_set_conv_mode(sts_engine* e, int mode);
+
+/* Per-stage device timing of the last run, measured with HIP events on the engine's own stream. */
+typedef struct sts_profile {
+    float ms_text_encoder, ms_duration, ms_flow, ms_decoder, ms_total_device;
+    float ms_decoder_mfma;          /* time of the pure conv_mfma launch sequence inside the decoder */
+    int32_t decoder_mfma_launches;
+    double flops_text_encoder, flops_duration, flops_flow, flops_decoder;   /* algorithmic (true-tap) FLOPs */
+    double flops_decoder_mfma;      /* FLOPs executed by the launches timed in ms_decoder_mfma */
+    double bytes_decoder_min;       /* algorithmic HBM bytes of the decoder (weights once + act in/out per conv) */
+    int64_t frames, samples, phonemes;
+} sts_profile;
+int sts_set_profiling(sts_engine* e, int enable);
+int sts_get_profile(const sts_engine* e, sts_profile* p);
+
+/* Stand-alone conv entry for op-level parity tests: y = conv1d(x) with x [Cin][L] on the host.
+ * w is the reference layout [out][k][in] (transposed: same).  mode as sts_set_conv_mode. */
+int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias,
+                     int32_t Cout, int32_t k, int32_t pad, int32_t dil, int32_t stride_transposed,
+                     int32_t depthwise, float in_slope, int32_t in_act, int mode, float** y, int32_t* Lout);
+
+void sts_free(void* p);
+const char* sts_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

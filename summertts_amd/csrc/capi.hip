@@ -1,0 +1,212 @@
+// capi.hip -- extern "C" surface declared in include/summertts_hip.h.
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "engine.hpp"
+
+using namespace sts;
+
+struct sts_engine { Engine eng; };
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& s) { g_err = s; return code; }
+
+extern "C" {
+
+const char* sts_last_error(void) { return g_err.c_str(); }
+void sts_free(void* p) { free(p); }
+
+int sts_create(const float* blob, int64_t blob_bytes, int device, sts_engine** out) {
+    if (!out) return set_err(STS_EINVAL, "sts_create: null out pointer");
+    *out = nullptr;
+    sts_engine* e = new (std::nothrow) sts_engine();
+    if (!e) return set_err(STS_EDEVICE, "out of host memory");
+    int rc = e->eng.init(blob, blob_bytes, device);
+    if (rc != STS_OK) { set_err(rc, e->eng.error()); delete e; return rc; }
+    *out = e;
+    return STS_OK;
+}
+
+void sts_destroy(sts_engine* e) { delete e; }
+
+int sts_speaker_num(const sts_engine* e) {
+    if (!e) return 1;
+    return e->eng.model.spk_num == 0 ? 1 : e->eng.model.spk_num;   // SynthesizerTrn.cpp:79-89
+}
+
+int sts_get_info(const sts_engine* e, sts_model_info* info) {
+    if (!e || !info) return set_err(STS_EINVAL, "null argument");
+    const Model& m = e->eng.model;
+    info->is_multi_speaker = m.is_ms; info->lang_type = m.lang; info->dur_pred_type = m.dur_type; info->dec_type = m.dec_type;
+    info->vocab = m.vocab; info->hidden = m.hidden; info->inter_channels = m.inter;
+    info->speaker_num = m.spk_num == 0 ? 1 : m.spk_num; info->gin_channels = m.gin;
+    info->samples_per_frame = m.hop_total; info->sample_rate = 16000;
+    info->blob_floats_consumed = m.consumed;
+    return STS_OK;
+}
+
+int sts_run_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int32_t* n, const int32_t* sid,
+                  const float* length_scale, int32_t* n_out, int64_t* total_out) {
+    if (!e) return set_err(STS_EINVAL, "null engine");
+    int rc = e->eng.run(B, ids, n, sid, length_scale);
+    if (rc != STS_OK) return set_err(rc, e->eng.error());
+    if (n_out) for (int b = 0; b < B; b++) n_out[b] = e->eng.n_samples[b];
+    if (total_out) *total_out = e->eng.total_samples;
+    return STS_OK;
+}
+
+int sts_copy_pcm_device(sts_engine* e, void* dst, int64_t cap) {
+    if (!e || !dst) return set_err(STS_EINVAL, "null argument");
+    if (cap < e->eng.total_samples || !e->eng.d_pcm) return set_err(STS_ESTATE, "destination too small or no run yet");
+    if (hipMemcpyAsync(dst, e->eng.d_pcm, (size_t)e->eng.total_samples * 2, hipMemcpyDeviceToDevice, e->eng.stream) != hipSuccess ||
+        hipStreamSynchronize(e->eng.stream) != hipSuccess)
+        return set_err(STS_EDEVICE, "device copy failed");
+    return STS_OK;
+}
+
+int sts_copy_pcm_host(sts_engine* e, int16_t* dst, int64_t cap) {
+    if (!e || !dst) return set_err(STS_EINVAL, "null argument");
+    if (cap < e->eng.total_samples || !e->eng.d_pcm) return set_err(STS_ESTATE, "destination too small or no run yet");
+    if (hipMemcpyAsync(dst, e->eng.d_pcm, (size_t)e->eng.total_samples * 2, hipMemcpyDeviceToHost, e->eng.stream) != hipSuccess ||
+        hipStreamSynchronize(e->eng.stream) != hipSuccess)
+        return set_err(STS_EDEVICE, "device-to-host copy failed");
+    return STS_OK;
+}
+
+int sts_infer_ids_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int32_t* n, const int32_t* sid,
+                        const float* length_scale, int16_t** pcm_out, int32_t* n_out) {
+    if (!pcm_out || !n_out) return set_err(STS_EINVAL, "null output");
+    int64_t total = 0;
+    int rc = sts_run_batch(e, B, ids, n, sid, length_scale, n_out, &total);
+    if (rc != STS_OK) return rc;
+    int16_t* all = (int16_t*)malloc((size_t)(total > 0 ? total : 1) * 2);
+    if (!all) return set_err(STS_EDEVICE, "out of host memory");
+    rc = sts_copy_pcm_host(e, all, total);
+    if (rc != STS_OK) { free(all); return rc; }
+    int64_t off = 0;
+    for (int b = 0; b < B; b++) {
+        if (B == 1) { pcm_out[0] = all; break; }   // single utterance: hand over the buffer itself
+        pcm_out[b] = (int16_t*)malloc((size_t)(n_out[b] > 0 ? n_out[b] : 1) * 2);
+        if (!pcm_out[b]) { free(all); return set_err(STS_EDEVICE, "out of host memory"); }
+        memcpy(pcm_out[b], all + off, (size_t)n_out[b] * 2);
+        off += n_out[b];
+    }
+    if (B != 1) free(all);
+    return STS_OK;
+}
+
+int sts_infer_ids(sts_engine* e, const int32_t* ids, int32_t n, int32_t sid, float length_scale, int16_t** pcm_out,
+                  int32_t* n_out) {
+    const int32_t* idp[1] = {ids};
+    return sts_infer_ids_batch(e, 1, idp, &n, &sid, &length_scale, pcm_out, n_out);
+}
+
+int sts_set_forced_durations(sts_engine* e, const int32_t* dur, int64_t count) {
+    if (!e) return set_err(STS_EINVAL, "null engine");
+    if (!dur || count <= 0) { e->eng.have_forced = false; return STS_OK; }
+    e->eng.forced_dur.assign(dur, dur + count);
+    e->eng.have_forced = true;
+    return STS_OK;
+}
+
+int sts_set_record_taps(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.record_taps = enable != 0; return STS_OK; }
+int sts_set_conv_mode(sts_engine* e, int mode) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.conv_mode = mode; return STS_OK; }
+int sts_set_profiling(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.profiling = enable != 0; return STS_OK; }
+
+int sts_get_profile(const sts_engine* e, sts_profile* p) {
+    if (!e || !p) return set_err(STS_EINVAL, "null argument");
+    *p = e->eng.prof;
+    return STS_OK;
+}
+
+int sts_get_tap(sts_engine* e, const char* name, float** data, int32_t* channels, int64_t* length) {
+    if (!e || !name || !data || !channels || !length) return set_err(STS_EINVAL, "null argument");
+    auto it = e->eng.taps.find(name);
+    if (it == e->eng.taps.end()) return set_err(STS_ESTATE, std::string("tap not recorded: ") + name);
+    const Tap& t = it->second;
+    float* p = (float*)malloc(t.data.size() * sizeof(float) + 4);
+    if (!p) return set_err(STS_EDEVICE, "out of host memory");
+    memcpy(p, t.data.data(), t.data.size() * sizeof(float));
+    *data = p; *channels = t.channels; *length = t.length;
+    return STS_OK;
+}
+
+int sts_get_durations(sts_engine* e, int32_t* dur, int64_t cap) {
+    if (!e || !dur) return set_err(STS_EINVAL, "null argument");
+    if ((int64_t)e->eng.durations_h.size() > cap) return set_err(STS_ESTATE, "destination too small");
+    memcpy(dur, e->eng.durations_h.data(), e->eng.durations_h.size() * sizeof(int32_t));
+    return STS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// op-level entry for the parity tests: one conv on host arrays through the same kernels
+int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias, int32_t Cout,
+                     int32_t k, int32_t pad, int32_t dil, int32_t stride_t, int32_t depthwise, float in_slope, int32_t in_act,
+                     int mode, float** y_out, int32_t* Lout_out) {
+    if (!x || !w || !y_out || !Lout_out || Cin <= 0 || Cout <= 0 || L <= 0 || k <= 0) return set_err(STS_EINVAL, "bad conv arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return set_err(STS_EDEVICE, "no HIP device visible (no CPU fallback)");
+    if (hipSetDevice(device) != hipSuccess) return set_err(STS_EDEVICE, "hipSetDevice failed");
+    const bool tr = stride_t > 0;
+    const int Lout = tr ? (L - 1) * stride_t - 2 * pad + (k - 1) + 1 : L + 2 * pad - dil * (k - 1);
+    if (Lout <= 0) return set_err(STS_EINVAL, "empty output");
+    auto r_up = [](int v, int m) { return (v + m - 1) / m * m; };
+    const int cin_eff = depthwise ? 1 : Cin;
+    const int Cin_pad = r_up(cin_eff, 16), Cout_pad = r_up(Cout, 32);
+    const int J = tr ? (k + stride_t - 1) / stride_t : 1;
+    const size_t wn = depthwise ? (size_t)k * Cout_pad : (tr ? (size_t)stride_t * J : (size_t)k) * Cin_pad * Cout_pad;
+    std::vector<float> wp(wn, 0.f), bp(Cout_pad, 0.f);
+    if (depthwise) {
+        for (int o = 0; o < Cout; o++) for (int t = 0; t < k; t++) wp[(size_t)t * Cout_pad + o] = w[(size_t)o * k + t];
+    } else if (tr) {
+        for (int ph = 0; ph < stride_t; ph++) for (int j = 0; j < J; j++) {
+            int kk = ph + j * stride_t; if (kk >= k) continue;
+            for (int ci = 0; ci < Cin; ci++) for (int o = 0; o < Cout; o++)
+                wp[(((size_t)ph * J + j) * Cin_pad + ci) * Cout_pad + o] = w[((size_t)o * k + kk) * Cin + ci];
+        }
+    } else {
+        for (int o = 0; o < Cout; o++) for (int t = 0; t < k; t++) for (int ci = 0; ci < Cin; ci++)
+            wp[((size_t)t * Cin_pad + ci) * Cout_pad + o] = w[((size_t)o * k + t) * Cin + ci];
+    }
+    if (bias) memcpy(bp.data(), bias, sizeof(float) * Cout);
+    float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr; int* dseg = nullptr;
+    int seg[2] = {0, 1};
+    bool ok = hipMalloc((void**)&dx, (size_t)Cin * L * 4) == hipSuccess && hipMalloc((void**)&dw, wn * 4) == hipSuccess &&
+              hipMalloc((void**)&db, (size_t)Cout_pad * 4) == hipSuccess && hipMalloc((void**)&dy, (size_t)Cout * Lout * 4) == hipSuccess &&
+              hipMalloc((void**)&dseg, 8) == hipSuccess;
+    int rc = STS_OK;
+    if (!ok) rc = set_err(STS_EDEVICE, "hipMalloc failed");
+    if (rc == STS_OK) {
+        (void)hipMemcpy(dx, x, (size_t)Cin * L * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dw, wp.data(), wn * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(db, bp.data(), (size_t)Cout_pad * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dseg, seg, 8, hipMemcpyHostToDevice);
+        (void)hipMemset(dy, 0, (size_t)Cout * Lout * 4);
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = dx; a.x_ld = L; a.y = dy; a.y_ld = Lout; a.w = dw; a.bias = bias ? db : nullptr;
+        a.Cin = cin_eff; a.Cout = Cout; a.Cin_pad = Cin_pad; a.Cout_pad = Cout_pad;
+        a.depthwise = depthwise ? 1 : 0;
+        if (tr) { a.ntap = J; a.tap_step = -1; a.tap_off = 0; a.out_stride = stride_t; a.out_off = -pad; a.transposed = 1; a.n_extra = J - 1; a.max_n = L + J - 1; }
+        else { a.ntap = k; a.tap_step = dil; a.tap_off = -pad; a.out_stride = 1; a.out_off = 0; a.max_n = Lout; }
+        a.in_act = in_act; a.in_slope = in_slope; a.epi = EPI_STORE;
+        // segment lengths in base units: in = L, out = Lout -> two views over the same {off=0,len=1} table
+        a.in_seg = SegView{dseg, dseg + 1, L, 0}; a.out_seg = SegView{dseg, dseg + 1, Lout, 0}; a.B = 1;
+        if (mode != 1 && conv_mfma_eligible(a)) conv_mfma(a, nullptr, mode >= 2 ? mode - 2 : -1);
+        else if (mode >= 2) rc = set_err(STS_EINVAL, "shape not eligible for the matrix-core kernel");
+        else conv_generic(a, nullptr);
+        if (rc == STS_OK && (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)) rc = set_err(STS_EDEVICE, "conv kernel failed");
+        if (rc == STS_OK) {
+            float* y = (float*)malloc((size_t)Cout * Lout * 4);
+            (void)hipMemcpy(y, dy, (size_t)Cout * Lout * 4, hipMemcpyDeviceToHost);
+            *y_out = y; *Lout_out = Lout;
+        }
+    }
+    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dseg);
+    return rc;
+}
+
+}  // extern "C"

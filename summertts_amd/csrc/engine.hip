@@ -1,0 +1,478 @@
+// engine.hip -- ids -> int16 PCM on one MI355X.  Restates the pipeline of
+// /root/reference/src/models/SynthesizerTrn.cpp:357-400 for a BATCH of utterances packed along time:
+//   TextEncoder -> duration predictor -> [one D2H of the frame counts] -> length regulator ->
+//   reverse flow -> decoder -> int16.
+// Everything runs on the engine's own HIP stream; the only host synchronisation inside a run is the
+// data-dependent frame count F (SynthesizerTrn.cpp:376-381).
+#include "engine.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace sts {
+
+#define HIPCK(call)                                                                           \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) return fail(STS_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+Engine::~Engine() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    free_model(model);
+    if (arenaT_.base) (void)hipFree(arenaT_.base);
+    if (arenaF_.base) (void)hipFree(arenaF_.base);
+    if (pinned_) (void)hipHostFree(pinned_);
+    if (have_events_) for (auto& e : ev_) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+int Engine::init(const float* blob, int64_t bytes, int dev) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(STS_EDEVICE, "no HIP device visible: the SummerTTS HIP engine needs an AMD GPU (gfx950) -- there is no CPU fallback");
+    if (dev < 0 || dev >= count) return fail(STS_EINVAL, "device index out of range");
+    device = dev;
+    HIPCK(hipSetDevice(dev));
+    HIPCK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto& e : ev_) HIPCK(hipEventCreate(&e));
+    have_events_ = true;
+    if (!blob || bytes < 32) return fail(STS_EMODEL, "model blob too small");
+    if (!load_model(blob, bytes / (int64_t)sizeof(float), model)) return fail(STS_EMODEL, "model parse failed: " + model.error);
+    return STS_OK;
+}
+
+bool Engine::ensure(Arena& a, size_t bytes) {
+    if (bytes <= a.cap) return true;
+    (void)hipStreamSynchronize(stream);
+    if (a.base) (void)hipFree(a.base);
+    a.base = nullptr; a.cap = 0;
+    size_t want = bytes + bytes / 4 + (1u << 20);
+    if (hipMalloc((void**)&a.base, want) != hipSuccess) { if (hipMalloc((void**)&a.base, bytes) != hipSuccess) return false; want = bytes; }
+    a.cap = want;
+    return true;
+}
+
+bool Engine::ensure_pinned(size_t bytes) {
+    if (bytes <= pinned_cap_) return true;
+    (void)hipStreamSynchronize(stream);
+    if (pinned_) (void)hipHostFree(pinned_);
+    pinned_ = nullptr; pinned_cap_ = 0;
+    size_t want = bytes * 2 + 4096;
+    if (hipHostMalloc((void**)&pinned_, want, hipHostMallocDefault) != hipSuccess) return false;
+    pinned_cap_ = want;
+    return true;
+}
+
+void Engine::stage_begin(int s) { cur_stage_ = s; }
+void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); }
+
+void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.x_ld = lin.ld; a.y = y; a.y_ld = lout.ld;
+    a.w = c.w; a.bias = c.bias; a.ubias = o.ubias; a.ubias_ld = lout.nb;
+    a.res = o.res; a.res_ld = o.res_ld ? o.res_ld : lout.ld;
+    a.aux = o.aux; a.aux_ld = o.aux_ld ? o.aux_ld : lout.ld;
+    a.pcm = o.pcm;
+    a.Cin = c.Cin; a.Cout = c.Cout; a.Cin_pad = c.Cin_pad; a.Cout_pad = c.Cout_pad;
+    if (c.transposed) {
+        a.ntap = c.J; a.tap_step = -1; a.tap_off = 0; a.out_stride = c.stride; a.out_off = -c.pad;
+        a.transposed = 1; a.n_extra = c.J - 1; a.max_n = lin.max_len + c.J - 1;
+    } else {
+        a.ntap = c.k; a.tap_step = c.dil; a.tap_off = -(o.pad_l >= 0 ? o.pad_l : c.pad); a.out_stride = 1; a.out_off = 0;
+        a.max_n = lout.max_len;
+    }
+    a.depthwise = c.depthwise;
+    a.in_act = o.in_act; a.in_slope = o.slope; a.in_reflect = o.reflect;
+    a.epi = o.epi; a.epi_flag = o.epi_flag; a.epi_scale = o.epi_scale; a.H = c.H; a.gate_perm = c.gate_perm;
+    a.in_seg = lin.seg; a.out_seg = lout.seg; a.B = lout.nb;
+    const double positions = c.transposed ? (double)lin.total : (double)lout.total;
+    const double fl = 2.0 * c.macs_per_out * positions;
+    flops_[cur_stage_] += fl;
+    if (cur_stage_ == 3) {
+        const size_t wfl = c.depthwise ? (size_t)c.k * c.Cout : (size_t)c.k * c.Cin * c.Cout;
+        dec_bytes_ += 4.0 * ((double)c.Cin * lin.total + (double)c.Cout * lout.total + (double)wfl);
+        if (o.res) dec_bytes_ += 4.0 * (double)c.Cout * lout.total;
+    }
+    const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
+    if (can_mfma) {
+        if (in_mfma_region_) { mfma_flops_ += fl; mfma_launches_++; }
+        conv_mfma(a, stream, conv_mode >= 2 ? conv_mode - 2 : -1);
+    } else {
+        conv_generic(a, stream);
+    }
+}
+
+void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu) {
+    LnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.a_ld = lv.ld; g.b = b; g.b_ld = lv.ld; g.res = res; g.res_ld = lv.ld; g.y = y; g.y_ld = lv.ld;
+    g.gamma = l.g; g.beta = l.b; g.C = l.C; g.pre_relu = pre_relu; g.post_gelu = post_gelu;
+    g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
+    layer_norm(g, stream);
+}
+
+// /root/reference/src/modules/DDSConv.cpp:84-111: x += gelu(LN2(conv1x1(gelu(LN1(dwconv(x))))))
+void Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv) {
+    for (int i = 0; i < d.n; i++) {
+        conv(d.sep[i], h, lv, t1, lv, ConvOpt());
+        ln(d.n1[i], t1, nullptr, nullptr, t1, lv, 0, 1);
+        conv(d.pw[i], t1, lv, t2, lv, ConvOpt());
+        ln(d.n2[i], t2, nullptr, h, h, lv, 0, 1);
+    }
+}
+
+void Engine::tap(const char* name, const float* d, int channels, long ld, long length) {
+    if (!record_taps) return;
+    Tap& t = taps[name];
+    t.channels = channels; t.length = length;
+    t.data.resize((size_t)channels * length);
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy2D(t.data.data(), (size_t)length * sizeof(float), d, (size_t)ld * sizeof(float),
+                      (size_t)length * sizeof(float), (size_t)channels, hipMemcpyDeviceToHost);
+}
+
+struct BufT {
+    int *meta_i; float* ls; int* ids; int* forced;
+    float *x, *qkv, *att, *y, *x1, *ffh, *m;
+    float *dh, *dt1, *dt2, *dc, *dhh, *dp29, *dr[4], *dlogw;
+    int *dur, *cum, *frames;
+    float *g, *cond_dp, *cond_dec, *cond_wn;
+};
+struct BufF {
+    float *z, *h, *acts, *out, *x0, *regA, *regB, *tailA, *tailB, *tailC, *wave, *fliptmp;
+    int16_t* pcm;
+};
+
+int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls) {
+    Model& M = model;
+    if (B <= 0 || !ids || !n) return fail(STS_EINVAL, "empty batch");
+    HIPCK(hipSetDevice(device));
+    taps.clear();
+    memset(&prof, 0, sizeof(prof));
+    for (double& f : flops_) f = 0;
+    mfma_flops_ = 0; dec_bytes_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+
+    // ---------------- host-side batch geometry (phoneme level)
+    std::vector<int> offT(B), lenT(B);
+    long Ttot = 0; int maxT = 0;
+    for (int b = 0; b < B; b++) {
+        if (n[b] <= 0 || !ids[b]) return fail(STS_EINVAL, "utterance with no phonemes");
+        for (int i = 0; i < n[b]; i++)
+            if (ids[b][i] < 0 || ids[b][i] >= M.vocab) return fail(STS_EINVAL, "phoneme id outside the model vocabulary");
+        offT[b] = (int)Ttot; lenT[b] = n[b]; Ttot += n[b]; if (n[b] > maxT) maxT = n[b];
+    }
+    if (Ttot > (1 << 24)) return fail(STS_EINVAL, "batch too large");
+    if ((size_t)(M.hidden / 2 + 8 + maxT) * 4 > 150 * 1024) return fail(STS_EINVAL, "utterance too long for the attention kernel");
+    if (have_forced && (long)forced_dur.size() != Ttot) { have_forced = false; return fail(STS_EINVAL, "forced durations do not match the batch"); }
+
+    const int H = M.hidden, C = M.inter;
+    const int FF = M.n_layers ? M.ffn[0].c1.Cout : 0;
+    const int fdp = M.dur_type == 0 ? M.sdp_pre.Cout : M.fix_c1.Cout;
+    const int wnH = M.n_flows ? M.cp[0].wn.H : 0;
+    const int wnL = M.n_flows ? M.cp[0].wn.n : 0;
+
+    BufT bt;
+    auto layoutT = [&](Arena& A) {
+        A.used = 0;
+        bt.meta_i = A.get<int>((size_t)7 * B + 8);
+        bt.ls = A.get<float>(B);
+        bt.ids = A.get<int>(Ttot);
+        bt.forced = A.get<int>(Ttot);
+        bt.x = A.get<float>((size_t)H * Ttot); bt.qkv = A.get<float>((size_t)3 * H * Ttot);
+        bt.att = A.get<float>((size_t)H * Ttot); bt.y = A.get<float>((size_t)H * Ttot);
+        bt.x1 = A.get<float>((size_t)H * Ttot); bt.ffh = A.get<float>((size_t)FF * Ttot);
+        bt.m = A.get<float>((size_t)C * Ttot);
+        bt.dh = A.get<float>((size_t)(fdp > H ? fdp : H) * Ttot); bt.dt1 = A.get<float>((size_t)fdp * Ttot);
+        bt.dt2 = A.get<float>((size_t)fdp * Ttot); bt.dc = A.get<float>((size_t)fdp * Ttot);
+        bt.dhh = A.get<float>((size_t)fdp * Ttot); bt.dp29 = A.get<float>((size_t)29 * Ttot);
+        for (auto& r : bt.dr) r = A.get<float>(Ttot);
+        bt.dlogw = A.get<float>(Ttot);
+        bt.dur = A.get<int>(Ttot + B); bt.cum = A.get<int>(Ttot);
+        bt.frames = bt.dur + Ttot;     // contiguous with dur: ONE D2H brings both
+        bt.g = A.get<float>((size_t)(M.gin > 0 ? M.gin : 1) * B);
+        bt.cond_dp = A.get<float>((size_t)(fdp > H ? fdp : H) * B);
+        bt.cond_dec = A.get<float>((size_t)(M.up_init > 0 ? M.up_init : 1) * B);
+        bt.cond_wn = A.get<float>((size_t)(2 * wnH * wnL + 1) * B);
+    };
+    arenaT_.measuring = true; layoutT(arenaT_);
+    if (!ensure(arenaT_, arenaT_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (phoneme-level workspace)");
+    arenaT_.measuring = false; layoutT(arenaT_);
+
+    // ---------------- one H2D: geometry + ids (+ forced durations)
+    const size_t meta_ints = (size_t)7 * B + 8;
+    const size_t up_bytes = (meta_ints + B + 2 * (size_t)Ttot) * 4 + 1024;
+    if (!ensure_pinned(up_bytes + ((size_t)Ttot + B) * 4)) return fail(STS_EDEVICE, "pinned host allocation failed");
+    int* pm = (int*)pinned_;
+    int* p_offT = pm, *p_lenT = pm + B, *p_sid = pm + 2 * B, *p_offF = pm + 3 * B, *p_lenF = pm + 4 * B, *p_one = pm + 5 * B;
+    for (int b = 0; b < B; b++) { p_offT[b] = offT[b]; p_lenT[b] = lenT[b]; p_sid[b] = sid ? sid[b] : 0; }
+    p_one[0] = 0; p_one[1] = B;
+    int* d_offT = bt.meta_i, *d_lenT = bt.meta_i + B, *d_sid = bt.meta_i + 2 * B, *d_offF = bt.meta_i + 3 * B,
+        *d_lenF = bt.meta_i + 4 * B, *d_one = bt.meta_i + 5 * B;
+    float* p_ls = (float*)(pm + meta_ints);
+    for (int b = 0; b < B; b++) p_ls[b] = ls ? ls[b] : 1.0f;
+    int* p_ids = (int*)(p_ls + B);
+    for (int b = 0; b < B; b++) memcpy(p_ids + offT[b], ids[b], sizeof(int) * n[b]);
+    int* p_forced = p_ids + Ttot;
+    if (have_forced) memcpy(p_forced, forced_dur.data(), sizeof(int) * Ttot);
+    HIPCK(hipMemcpyAsync(bt.meta_i, pm, meta_ints * 4, hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemcpyAsync(bt.ls, p_ls, (size_t)B * 4, hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemcpyAsync(bt.ids, p_ids, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
+    if (have_forced) HIPCK(hipMemcpyAsync(bt.forced, p_forced, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
+
+    Lvl lvT; lvT.seg = SegView{d_offT, d_lenT, 1, 0}; lvT.nb = B; lvT.max_len = maxT; lvT.total = Ttot; lvT.ld = Ttot;
+    Lvl lvB; lvB.seg = SegView{d_one, d_one + 1, 1, 0}; lvB.nb = 1; lvB.max_len = B; lvB.total = B; lvB.ld = B;
+
+    mark(0);
+    // ---------------- TextEncoder (/root/reference/src/models/TextEncoder.cpp:50-74, attention_encoder.cpp:78-94)
+    stage_begin(0);
+    embed(bt.ids, M.emb, M.vocab, M.emb_size, sqrtf((float)M.hidden), bt.x, Ttot, (int)Ttot, stream);
+    for (int l = 0; l < M.n_layers; l++) {
+        const DMha& a = M.mha[l];
+        conv(a.qkv, bt.x, lvT, bt.qkv, lvT, ConvOpt());
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.q = bt.qkv; at.k = bt.qkv + (size_t)H * Ttot; at.v = bt.qkv + (size_t)2 * H * Ttot; at.o = bt.att; at.ld = Ttot;
+        at.relk = a.relk; at.relv = a.relv; at.kc = a.kc; at.px = a.px; at.win = a.win; at.nheads = 2;
+        at.seg = lvT.seg; at.B = B; at.max_len = maxT;
+        attention(at, stream);
+        flops_[0] += 2.0 * 2.0 * (double)a.ch * (double)maxT * (double)Ttot;   // ~ QK^T + PV
+        conv(a.o, bt.att, lvT, bt.y, lvT, ConvOpt());
+        ln(M.ln1[l], bt.x, bt.y, nullptr, bt.x1, lvT, 0, 0);
+        const DFfn& f = M.ffn[l];
+        ConvOpt o1; o1.pad_l = f.ksize == 1 ? 0 : (f.ksize - 1) / 2;
+        conv(f.c1, bt.x1, lvT, bt.ffh, lvT, o1);
+        ConvOpt o2 = o1; o2.in_act = 1; o2.slope = 0.f;   // nn_relu fused into the consumer's staging
+        conv(f.c2, bt.ffh, lvT, bt.y, lvT, o2);
+        ln(M.ln2[l], bt.x1, bt.y, nullptr, bt.x, lvT, 0, 0);
+    }
+    conv(M.proj, bt.x, lvT, bt.m, lvT, ConvOpt());
+    tap("x_enc", bt.x, H, Ttot, Ttot);
+    tap("m", bt.m, C, Ttot, Ttot);
+    mark(1);
+
+    // ---------------- speaker conditioning vectors (all 1x1 convs on g; SynthesizerTrn.cpp:363-372)
+    stage_begin(1);
+    const bool ms = M.is_ms == 1;
+    if (ms) gather_speaker(M.emb_g, M.spk_num, M.gin, d_sid, B, bt.g, stream);
+
+    // ---------------- duration predictor
+    const float* r_final = nullptr;
+    if (M.dur_type == 0) {   // /root/reference/src/models/StochasticDurationPredictor.cpp:117-149
+        ConvOpt op;
+        if (ms) { conv(M.sdp_cond, bt.g, lvB, bt.cond_dp, lvB, ConvOpt()); op.ubias = bt.cond_dp; }
+        conv(M.sdp_pre, bt.x, lvT, bt.dh, lvT, op);
+        dds(M.sdp_dds, bt.dh, bt.dt1, bt.dt2, lvT);
+        conv(M.sdp_proj, bt.dh, lvT, bt.dc, lvT, ConvOpt());
+        fill_zero(bt.dr[0], Ttot, stream); fill_zero(bt.dr[1], Ttot, stream);
+        float *r0 = bt.dr[0], *r1 = bt.dr[1], *n0 = bt.dr[2], *n1 = bt.dr[3];
+        for (int i = M.sdp_flows - 1; i > 0; i--) {   // flow 0 is skipped; z == 0 because noise_scale == 0
+            const DConvFlow& cf = M.cf[i];
+            Lvl l1 = lvT;
+            conv(cf.pre, r0, l1, bt.dhh, lvT, ConvOpt());
+            add_inplace(bt.dhh, Ttot, bt.dc, Ttot, cf.filter, Ttot, stream);
+            dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT);
+            conv(cf.proj, bt.dhh, lvT, bt.dp29, lvT, ConvOpt());
+            spline_step(bt.dp29, Ttot, sqrtf((float)cf.filter), r0, r1, n0, n1, Ttot, stream);
+            float* t;
+            t = r0; r0 = n0; n0 = t;
+            t = r1; r1 = n1; n1 = t;
+        }
+        r_final = r0;
+    } else {                 // /root/reference/src/models/FixDurationPredictor.cpp:75-96
+        const float* xin = bt.x;
+        if (ms) {
+            conv(M.fix_cond, bt.g, lvB, bt.cond_dp, lvB, ConvOpt());
+            HIPCK(hipMemcpyAsync(bt.dh, bt.x, (size_t)H * Ttot * 4, hipMemcpyDeviceToDevice, stream));
+            add_ubias(bt.dh, Ttot, bt.cond_dp, H, lvT.seg, B, maxT, stream);
+            xin = bt.dh;
+        }
+        conv(M.fix_c1, xin, lvT, bt.dt1, lvT, ConvOpt());
+        ln(M.fix_n1, bt.dt1, nullptr, nullptr, bt.dt1, lvT, 1, 0);
+        conv(M.fix_c2, bt.dt1, lvT, bt.dt2, lvT, ConvOpt());
+        ln(M.fix_n2, bt.dt2, nullptr, nullptr, bt.dt2, lvT, 1, 0);
+        conv(M.fix_proj, bt.dt2, lvT, bt.dr[0], lvT, ConvOpt());
+        r_final = bt.dr[0];
+    }
+    durations(r_final, M.dur_type == 0 ? 1 : 0, M.ea_m, M.ea_logs, bt.ls, have_forced ? bt.forced : nullptr, bt.dlogw,
+              bt.dur, bt.cum, bt.frames, lvT.seg, B, stream);
+    have_forced = false;
+    mark(2);
+    // ---------------- the one data-dependent sync: frame counts (+ durations for the API)
+    int* p_down = (int*)(pinned_ + up_bytes);
+    HIPCK(hipMemcpyAsync(p_down, bt.dur, ((size_t)Ttot + B) * 4, hipMemcpyDeviceToHost, stream));
+    HIPCK(hipStreamSynchronize(stream));
+    durations_h.assign(p_down, p_down + Ttot);
+    tap("logw", bt.dlogw, 1, Ttot, Ttot);
+    long Ftot = 0; int maxF = 0;
+    for (int b = 0; b < B; b++) {
+        int f = p_down[Ttot + b];
+        p_offF[b] = (int)Ftot; p_lenF[b] = f; Ftot += f; if (f > maxF) maxF = f;
+    }
+    const int hop = M.hop_total;
+    if ((double)Ftot * hop > 2.0e9 || (double)Ftot * hop * 8 > 6.0e10) return fail(STS_EINVAL, "batch produces too many samples for one call");
+    HIPCK(hipMemcpyAsync(d_offF, p_offF, (size_t)2 * B * 4, hipMemcpyHostToDevice, stream));
+
+    // ---------------- frame-level workspace
+    int upS = 1;
+    for (int u : M.up_rate) upS *= u;
+    std::vector<size_t> stage_elems(M.n_up);
+    size_t regA = 0, regB = 0;
+    { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)5 * M.ups[i].Cout * Ftot * S;
+          if (i & 1) { if (stage_elems[i] > regB) regB = stage_elems[i]; } else { if (stage_elems[i] > regA) regA = stage_elems[i]; } } }
+    const long Lsb = Ftot * upS + B;           // MB-iSTFT: frames + 1 per utterance
+    const int sbC = M.conv_post.Cout;
+    BufF bf;
+    auto layoutF = [&](Arena& A) {
+        A.used = 0;
+        bf.z = A.get<float>((size_t)C * Ftot); bf.h = A.get<float>((size_t)wnH * Ftot);
+        bf.acts = A.get<float>((size_t)wnH * Ftot); bf.out = A.get<float>((size_t)wnH * Ftot);
+        bf.fliptmp = A.get<float>((M.n_flows & 1) ? (size_t)C * Ftot : 1);
+        bf.x0 = A.get<float>((size_t)M.up_init * Ftot);
+        bf.regA = A.get<float>(regA + 1); bf.regB = A.get<float>(regB + 1);
+        if (M.dec_type != 0) {
+            bf.tailA = A.get<float>((size_t)sbC * Lsb); bf.tailB = A.get<float>((size_t)sbC * Lsb);
+            bf.tailC = A.get<float>((size_t)4 * Ftot * upS * 4);
+        } else { bf.tailA = bf.tailB = bf.tailC = nullptr; }
+        bf.wave = A.get<float>(record_taps ? (size_t)Ftot * hop : 1);
+        bf.pcm = A.get<int16_t>((size_t)Ftot * hop);
+    };
+    arenaF_.measuring = true; layoutF(arenaF_);
+    if (!ensure(arenaF_, arenaF_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (frame-level workspace)");
+    arenaF_.measuring = false; layoutF(arenaF_);
+
+    auto lvF = [&](int scale, int extra) {
+        Lvl l; l.seg = SegView{d_offF, d_lenF, scale, extra}; l.nb = B; l.max_len = maxF * scale + extra;
+        l.total = Ftot * scale + (long)B * extra; l.ld = l.total;
+        return l;
+    };
+    const Lvl lv1 = lvF(1, 0);
+    mark(7);
+    // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
+    stage_begin(2);
+    expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream);
+    tap("z_p", bf.z, C, Ftot, Ftot);
+
+    // ---------------- reverse flow (ResidualCouplingBlock.cpp:59-70, ResidualCouplingLayer.cpp:47-66, WN.cpp:100-149)
+    const int half = C / 2;
+    for (int i = M.n_flows - 1; i >= 0; i--) {
+        const DCoupling& cp = M.cp[i];
+        const float* x0 = bf.z + (size_t)(cp.flipped ? half : 0) * Ftot;
+        float* dst = bf.z + (size_t)(cp.flipped ? 0 : half) * Ftot;
+        const DWn& w = cp.wn;
+        if (w.has_cond) conv(w.cond, bt.g, lvB, bt.cond_wn, lvB, ConvOpt());
+        conv(cp.pre, x0, lv1, bf.h, lv1, ConvOpt());
+        for (int l = 0; l < w.n; l++) {
+            ConvOpt og; og.epi = EPI_GATE;
+            if (w.has_cond) og.ubias = bt.cond_wn + (size_t)l * 2 * w.H * B;
+            conv(w.in[l], bf.h, lv1, bf.acts, lv1, og);
+            ConvOpt orr; orr.epi = EPI_RESSKIP; orr.epi_flag = l == 0 ? 1 : 0; orr.aux = bf.out;
+            conv(w.rs[l], bf.acts, lv1, bf.h, lv1, orr);
+        }
+        ConvOpt os; os.epi = EPI_SUB;
+        conv(cp.post, bf.out, lv1, dst, lv1, os);
+    }
+    if (M.n_flows & 1) flip_channels(bf.z, Ftot, C, Ftot, bf.fliptmp, stream);
+    tap("z", bf.z, C, Ftot, Ftot);
+    mark(3);
+
+    // ---------------- decoder trunk (Generator_hifigan.cpp:139-175 and the identical loops of MS/Istft/MBB)
+    stage_begin(3);
+    {
+        ConvOpt op;
+        if (M.dec_type == 0 && ms) { conv(M.dec_cond, bt.g, lvB, bt.cond_dec, lvB, ConvOpt()); op.ubias = bt.cond_dec; }
+        conv(M.conv_pre, bf.z, lv1, bf.x0, lv1, op);
+    }
+    const float* x = bf.x0;
+    int S = 1;
+    Lvl lx = lv1;
+    mark(5);
+    in_mfma_region_ = true;
+    for (int i = 0; i < M.n_up; i++) {
+        const DConv& up = M.ups[i];
+        const int S2 = S * M.up_rate[i];
+        const Lvl l2 = lvF(S2, 0);
+        const size_t ce = (size_t)up.Cout * l2.total;
+        float* reg = (i & 1) ? bf.regB : bf.regA;
+        float *bup = reg, *t1 = reg + ce, *pa = reg + 2 * ce, *pb = reg + 3 * ce, *xs = reg + 4 * ce;
+        ConvOpt ou; ou.in_act = 1; ou.slope = 0.1f;
+        conv(up, x, lx, bup, l2, ou);
+        for (int j = 0; j < M.n_resk; j++) {   // /root/reference/src/modules/ResBlock1.cpp:55-69
+            const DResBlock& rb = M.rb[(size_t)i * M.n_resk + j];
+            const float* cur = bup;
+            const int nd = (int)rb.c1.size();
+            for (int d = 0; d < nd; d++) {
+                ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
+                conv(rb.c1[d], cur, l2, t1, l2, o1);
+                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur;
+                if (d < nd - 1) {
+                    float* nxt = (cur == pa) ? pb : pa;
+                    o2.epi = EPI_RESADD;
+                    conv(rb.c2[d], t1, l2, nxt, l2, o2);
+                    cur = nxt;
+                } else {       // xs = (rb_0 + rb_1 + ...) / nResK  (Generator_hifigan.cpp:159-173)
+                    o2.epi = EPI_RESADD_ACC; o2.aux = xs; o2.epi_scale = (float)M.n_resk;
+                    o2.epi_flag = j == 0 ? (M.n_resk == 1 ? 2 : 0) : (j == M.n_resk - 1 ? 2 : 1);
+                    if (M.n_resk == 1) { fill_zero(xs, (long)ce, stream); }
+                    conv(rb.c2[d], t1, l2, nullptr, l2, o2);
+                }
+            }
+        }
+        x = xs; S = S2; lx = l2;
+    }
+    in_mfma_region_ = false;
+    mark(6);
+
+    // ---------------- decoder tail
+    float* wave = record_taps ? bf.wave : nullptr;
+    const long Ntot = Ftot * hop;
+    if (M.dec_type == 0) {          // Generator_hifigan.cpp:177-179 + SynthesizerTrn.cpp:389-396
+        ConvOpt o; o.in_act = 1; o.slope = 1e-2f; o.epi = EPI_TANH_PCM; o.pcm = bf.pcm; o.aux = wave;
+        conv(M.conv_post, x, lx, nullptr, lx, o);
+    } else {                        // Generator_MBB.cpp:174-202, Generator_MS.cpp:198-228, Generator_Istft.cpp:180-197
+        const Lvl lsb = lvF(S, 1);
+        ConvOpt o; o.in_act = 1; o.slope = 1e-2f; o.reflect = 1;
+        conv(M.conv_post, x, lx, bf.tailA, lsb, o);
+        istft_spectrum(bf.tailA, lsb.ld, sbC, bf.tailB, lsb.total, stream);
+        const int bands = M.dec_type == 2 ? 1 : 4;
+        const Lvl ltm = lvF(S * 4, 0);
+        float* tm = bf.tailC;
+        istft_ola(bf.tailB, lsb.ld, bands, 18, lsb.seg, tm, ltm.ld, ltm.seg, B, ltm.max_len, stream);
+        if (M.dec_type == 2) {
+            quantize_pcm(tm, bf.pcm, Ntot, stream);
+            if (wave) HIPCK(hipMemcpyAsync(wave, tm, (size_t)Ntot * 4, hipMemcpyDeviceToDevice, stream));
+        } else {
+            const Lvl lo = lvF(S * 16, 0);
+            synth_fir(tm, ltm.ld, ltm.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, wave, bf.pcm, lo.seg, B,
+                      ltm.max_len, stream);
+        }
+        flops_[3] += 2.0 * (double)Ntot * (16.0 * 4 + 4 * 18 * 4 / 4.0);
+    }
+    mark(4);
+    if (wave) tap("wave", wave, 1, Ntot, Ntot);
+
+    d_pcm = bf.pcm;
+    total_samples = Ntot;
+    n_samples.resize(B);
+    for (int b = 0; b < B; b++) n_samples[b] = p_lenF[b] * hop;
+    HIPCK(hipStreamSynchronize(stream));
+    HIPCK(hipGetLastError());
+
+    prof.frames = Ftot; prof.samples = Ntot; prof.phonemes = Ttot;
+    prof.flops_text_encoder = flops_[0]; prof.flops_duration = flops_[1]; prof.flops_flow = flops_[2]; prof.flops_decoder = flops_[3];
+    prof.flops_decoder_mfma = mfma_flops_; prof.decoder_mfma_launches = mfma_launches_; prof.bytes_decoder_min = dec_bytes_ + 2.0 * (double)Ntot;
+    if (profiling) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, ev_[0], ev_[1]); prof.ms_text_encoder = t;
+        (void)hipEventElapsedTime(&t, ev_[1], ev_[2]); prof.ms_duration = t;
+        (void)hipEventElapsedTime(&t, ev_[7], ev_[3]); prof.ms_flow = t;
+        (void)hipEventElapsedTime(&t, ev_[3], ev_[4]); prof.ms_decoder = t;
+        (void)hipEventElapsedTime(&t, ev_[5], ev_[6]); prof.ms_decoder_mfma = t;
+        prof.ms_total_device = prof.ms_text_encoder + prof.ms_duration + prof.ms_flow + prof.ms_decoder;
+    }
+    return STS_OK;
+}
+
+}  // namespace sts

@@ -1,0 +1,87 @@
+// engine.hpp -- the batched acoustic pipeline on one MI355X: owns the HIP stream, the device-resident
+// model, two workspace arenas (phoneme-level and frame-level) and a pinned staging buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/summertts_hip.h"
+#include "kernels.hpp"
+#include "model.hpp"
+
+namespace sts {
+
+struct Arena {
+    char* base = nullptr; size_t cap = 0, used = 0; bool measuring = false;
+    void* alloc(size_t bytes) {
+        size_t a = (used + 255) & ~(size_t)255;
+        used = a + bytes;
+        if (measuring) return nullptr;
+        return base + a;
+    }
+    template <typename T> T* get(size_t count) { return (T*)alloc(count * sizeof(T)); }
+};
+
+// one packed level of the pipeline: which segments, how long, how many positions in total
+struct Lvl {
+    SegView seg; int nb = 0; int max_len = 0; long total = 0; long ld = 0;
+};
+
+struct ConvOpt {
+    int in_act = 0; float slope = 0.f; int reflect = 0;
+    int epi = EPI_STORE, epi_flag = 0; float epi_scale = 1.f;
+    const float* res = nullptr; long res_ld = 0;
+    float* aux = nullptr; long aux_ld = 0;
+    int16_t* pcm = nullptr;
+    const float* ubias = nullptr;
+    int pad_l = -1;            // override the left padding (FFN same_padding)
+};
+
+struct Tap { std::vector<float> data; int channels = 0; long length = 0; };
+
+class Engine {
+public:
+    ~Engine();
+    int init(const float* blob, int64_t bytes, int device);
+    int run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls);
+    const std::string& error() const { return err_; }
+
+    Model model;
+    int device = 0;
+    // results of the last run
+    std::vector<int32_t> n_samples;    // per utterance
+    int64_t total_samples = 0;
+    int16_t* d_pcm = nullptr;          // device, packed
+    std::vector<int32_t> durations_h;  // packed
+    std::map<std::string, Tap> taps;
+    sts_profile prof{};
+    // controls
+    std::vector<int32_t> forced_dur; bool have_forced = false;
+    bool record_taps = false, profiling = false;
+    int conv_mode = 0;
+    hipStream_t stream = nullptr;
+
+private:
+    int fail(int code, const std::string& msg) { err_ = msg; return code; }
+    bool ensure(Arena& a, size_t bytes);
+    bool ensure_pinned(size_t bytes);
+    void conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o);
+    void ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu);
+    void dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv);
+    void tap(const char* name, const float* d, int channels, long ld, long length);
+    void stage_begin(int s);
+    void mark(int i);
+
+    std::string err_;
+    Arena arenaT_, arenaF_;
+    char* pinned_ = nullptr; size_t pinned_cap_ = 0;
+    hipEvent_t ev_[8] = {};
+    bool have_events_ = false;
+    int cur_stage_ = 0;
+    double flops_[4] = {0, 0, 0, 0};
+    double mfma_flops_ = 0, dec_bytes_ = 0; int mfma_launches_ = 0; bool in_mfma_region_ = false;
+};
+
+}  // namespace sts

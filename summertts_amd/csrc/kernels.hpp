@@ -1,0 +1,113 @@
+// kernels.hpp -- device-kernel interface of the MI355X (gfx950) SummerTTS acoustic engine.
+//
+// Activation layout (same memory order as the reference's column-major Eigen MatrixXf [time, chan],
+// /root/reference/src/header/nn_conv1d.h:13-29): channel-major, time contiguous, fp32.  A batch of
+// utterances is PACKED along the time axis of one buffer  a[c * ld + pos]; a SegView says where
+// utterance b lives so that convolution halos never cross utterance boundaries.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sts {
+
+// Utterance b occupies positions [off[b]*scale + b*extra, ... + len[b]*scale + extra) of a packed row.
+// off/len are in "base units" (phonemes for the text-side buffers, frames for the acoustic side);
+// scale is the upsampling factor accumulated so far; extra is 1 for the MB-iSTFT tail (frames+1 rows).
+struct SegView {
+    const int* off;
+    const int* len;
+    int scale;
+    int extra;
+};
+
+enum Epilogue : int {
+    EPI_STORE = 0,       // y = v
+    EPI_RESADD = 1,      // y = v + res
+    EPI_RESADD_ACC = 2,  // t = v + res ; aux = (flag==0 ? t : flag==1 ? aux + t : (aux + t) / scale)   (ResBlock sum)
+    EPI_SUB = 3,         // y = y - v                                       (coupling: x1 -= m)
+    EPI_GATE = 4,        // y = tanh(v_t) * sigmoid(v_s)                     (WN gated unit)
+    EPI_RESSKIP = 5,     // rows <  H: y[row] += v ; rows >= H: aux[row-H] (+)= v   (WN res/skip)
+    EPI_TANH_PCM = 6,    // wave = tanh(v) ; pcm = trunc(wave * 32737)       (HiFi-GAN tail, Cout == 1)
+};
+
+struct ConvArgs {
+    const float* x; long x_ld;      // input  [Cin][x_ld]
+    float* y; long y_ld;            // output [Cout][y_ld]
+    const float* w;                 // packed weights [ntap][Cin_pad][Cout_pad] (co contiguous); depthwise: [ntap][Cout_pad]
+    const float* bias;              // [Cout_pad] (packed row order) or null
+    const float* ubias; int ubias_ld;  // per-utterance bias [Cout][ubias_ld = B] or null
+    const float* res; long res_ld;  // residual input (EPI_RESADD*)
+    float* aux; long aux_ld;        // accumulator (EPI_RESADD_ACC) / skip output (EPI_RESSKIP) / float wave (EPI_TANH_PCM)
+    int16_t* pcm;                   // EPI_TANH_PCM
+    int Cin, Cout, Cin_pad, Cout_pad, ntap;
+    int tap_step, tap_off;          // input position of output n, tap j: n + j*tap_step + tap_off
+    int out_stride, out_off;        // output position of n: n*out_stride + out_off (polyphase transposed conv)
+    int transposed, n_extra;        // n runs over [0, transposed ? in_len + n_extra : out_len)
+    int depthwise;
+    int in_act; float in_slope;     // input activation: 0 none, 1 leaky-relu(slope) (slope 0 == relu)
+    int in_reflect;                 // logical input = reflect-pad-left-1 view of x (MB-iSTFT tail)
+    int epi, epi_flag; float epi_scale; int H;
+    int gate_perm;                  // EPI_GATE rows are packed in (tanh32, sigmoid32) tile pairs
+    SegView in_seg, out_seg;
+    int B, max_n;                   // batch size, max n_count over the batch (grid sizing)
+};
+
+struct LnArgs {
+    const float* a; long a_ld;      // v = a (+ b)
+    const float* b; long b_ld;
+    const float* res; long res_ld;  // out = res + f(v) when non-null
+    float* y; long y_ld;
+    const float* gamma; const float* beta;
+    int C;
+    int pre_relu, post_gelu;
+    SegView seg; int B, max_len;
+};
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v; float* o; long ld;
+    const float* relk; const float* relv;   // [kc][px] (reference column-major [px, kc])
+    int kc, px, win, nheads;
+    SegView seg; int B, max_len;
+};
+
+// ---- launchers (all asynchronous on `st`) ------------------------------------------------------
+// Matrix-core (v_mfma_f32_32x32x2_f32) implicit-GEMM conv.  Returns false when the shape is not
+// eligible (caller then uses conv_generic).  `tile` < 0 picks a tile configuration heuristically.
+bool conv_mfma_eligible(const ConvArgs& a);
+void conv_mfma(const ConvArgs& a, hipStream_t st, int tile = -1);
+void conv_generic(const ConvArgs& a, hipStream_t st);
+
+void embed(const int* ids, const float* emb, int vocab, int H, float scale, float* x, long ld, int total, hipStream_t st);
+void layer_norm(const LnArgs& a, hipStream_t st);
+void attention(const AttnArgs& a, hipStream_t st);
+void add_inplace(float* y, long y_ld, const float* x, long x_ld, int C, long n, hipStream_t st);
+// y[c][seg b] += u[c*B + b]
+void add_ubias(float* y, long ld, const float* u, int C, SegView seg, int B, int max_len, hipStream_t st);
+void gather_speaker(const float* emb_g, int spk_num, int gin, const int* sid, int B, float* g, hipStream_t st);
+void fill_zero(float* p, long n, hipStream_t st);
+void flip_channels(float* x, long ld, int C, long n, float* tmp, hipStream_t st);
+
+// SDP spline step: (r0, r1) -> (spline^-1(r1 | h), r0) ; h = [29][ld]
+void spline_step(const float* h, long ld, float filter_sqrt, const float* r0, const float* r1,
+                 float* o0, float* o1, long n, hipStream_t st);
+// logw -> durations.  sdp: logw = (r0 - ea_m) * exp(-ea_logs) (ElementwiseAffine inverse) else logw = r0.
+// dur[pos] = forced ? forced[pos] : (int)ceil(exp(logw) * ls[b]);  cum[pos] = inclusive prefix inside the
+// utterance;  frames[b] = max(sum, 1).
+void durations(const float* r0, int sdp, float ea_m, float ea_logs, const float* ls, const int* forced,
+               float* logw_out, int* dur, int* cum, int* frames, SegView seg, int B, hipStream_t st);
+// z[c][offF[b] + f] = m[c][offT[b] + phoneme(f)]
+void expand_frames(const float* m, long m_ld, const int* cum, SegView segT, SegView segF, int C,
+                   float* z, long z_ld, int B, int max_frames, hipStream_t st);
+
+// MB-iSTFT tail.  sb: subband conv output [nb*18 or 18][ld] with per-utterance frames = 16*len+1.
+// spec: [bands*18][ld] (re, im per bin) ; tm: [bands][ld4] with per-utterance n = 4*(frames-1).
+void istft_spectrum(const float* sb, long ld, int rows, float* spec, long total, hipStream_t st);
+void istft_ola(const float* spec, long ld, int bands, int band_rows, SegView seg_frames, float* tm, long tm_ld,
+               SegView seg_tm, int B, int max_n, hipStream_t st);
+// polyphase synthesis FIR over the x4 zero-stuffed band signals: out[i] = sum_tau sum_b g*tm[b][(i+tau-pad)/4]*fir[tau*4+b]
+void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, int ntap, int pad, float gain,
+               float* wave, int16_t* pcm, SegView seg_out, int B, int max_n, hipStream_t st);
+// pcm = (int16)(int32)(wave * 32737)   (SynthesizerTrn.cpp:389-396: truncation, wrap-around)
+void quantize_pcm(const float* wave, int16_t* pcm, long n, hipStream_t st);
+
+}  // namespace sts

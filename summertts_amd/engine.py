@@ -1,0 +1,215 @@
+"""ctypes binding of ``libsummertts_hip.so`` (C ABI: ``include/summertts_hip.h``).
+
+This is host-side plumbing only: every call goes straight to the HIP engine; there is NO CPU
+fallback -- if the shared library or a GPU is missing the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsummertts_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+def build_library(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``summertts_amd/lib/libsummertts_hip.so`` (in-tree)."""
+    subprocess.run(["make", "-C", CSRC, "-j8"], check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [("is_multi_speaker", C.c_int32), ("lang_type", C.c_int32), ("dur_pred_type", C.c_int32),
+                ("dec_type", C.c_int32), ("vocab", C.c_int32), ("hidden", C.c_int32), ("inter_channels", C.c_int32),
+                ("speaker_num", C.c_int32), ("gin_channels", C.c_int32), ("samples_per_frame", C.c_int32),
+                ("sample_rate", C.c_int32), ("blob_floats_consumed", C.c_int64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms_text_encoder", C.c_float), ("ms_duration", C.c_float), ("ms_flow", C.c_float),
+                ("ms_decoder", C.c_float), ("ms_total_device", C.c_float), ("ms_decoder_mfma", C.c_float),
+                ("decoder_mfma_launches", C.c_int32), ("flops_text_encoder", C.c_double),
+                ("flops_duration", C.c_double), ("flops_flow", C.c_double), ("flops_decoder", C.c_double),
+                ("flops_decoder_mfma", C.c_double), ("bytes_decoder_min", C.c_double), ("frames", C.c_int64),
+                ("samples", C.c_int64), ("phonemes", C.c_int64)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.sts_last_error.restype = C.c_char_p
+    lib.sts_create.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+    lib.sts_destroy.argtypes = [C.c_void_p]
+    lib.sts_speaker_num.argtypes = [C.c_void_p]
+    lib.sts_get_info.argtypes = [C.c_void_p, C.POINTER(ModelInfo)]
+    lib.sts_infer_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                  C.POINTER(C.POINTER(C.c_int16)), C.POINTER(C.c_int32)]
+    lib.sts_run_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(C.c_int64)]
+    lib.sts_copy_pcm_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.sts_copy_pcm_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.sts_set_forced_durations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.sts_set_record_taps.argtypes = [C.c_void_p, C.c_int]
+    lib.sts_set_conv_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.sts_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.sts_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
+    lib.sts_get_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int64)]
+    lib.sts_get_durations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.sts_free.argtypes = [C.c_void_p]
+    lib.sts_debug_conv1d.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                     C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32)]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "sts_create", "sts_destroy", "sts_speaker_num", "sts_get_info", "sts_infer_ids", "sts_infer_ids_batch",
+    "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
+    "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_profiling",
+    "sts_get_profile", "sts_debug_conv1d", "sts_free", "sts_last_error",
+]
+
+
+class StsError(RuntimeError):
+    pass
+
+
+def _check(lib, rc: int):
+    if rc != 0:
+        raise StsError(f"sts error {rc}: {lib.sts_last_error().decode(errors='replace')}")
+
+
+class Synthesizer:
+    """Python mirror of the reference's ``SynthesizerTrn`` (include/SynthesizerTrn.h) at the phoneme-id
+    boundary: construct from a model blob, ``infer_ids`` -> int16 PCM.  Adds the batched entry."""
+
+    def __init__(self, blob: np.ndarray, device: int = 0):
+        self.lib = load_library()
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self.h = C.c_void_p()
+        _check(self.lib, self.lib.sts_create(blob.ctypes.data, blob.nbytes, device, C.byref(self.h)))
+        self.info = ModelInfo()
+        _check(self.lib, self.lib.sts_get_info(self.h, C.byref(self.info)))
+
+    # -- reference surface -------------------------------------------------------------------
+    def get_speaker_num(self) -> int:
+        return int(self.lib.sts_speaker_num(self.h))
+
+    def infer_ids(self, ids: Sequence[int], sid: int = 0, length_scale: float = 1.0) -> np.ndarray:
+        return self.infer_batch([ids], [sid], [length_scale])[0]
+
+    # -- batched -----------------------------------------------------------------------------
+    def run_batch(self, ids: Sequence[Sequence[int]], sid: Optional[Sequence[int]] = None,
+                  length_scale: Optional[Sequence[float]] = None) -> np.ndarray:
+        """Runs the batch and leaves the PCM on the device; returns per-utterance sample counts."""
+        B = len(ids)
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in ids]
+        ptrs = (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
+        n = np.asarray([a.size for a in arrs], dtype=np.int32)
+        sidv = np.zeros(B, np.int32) if sid is None else np.ascontiguousarray(sid, dtype=np.int32)
+        lsv = np.ones(B, np.float32) if length_scale is None else np.ascontiguousarray(length_scale, dtype=np.float32)
+        n_out = np.zeros(B, np.int32)
+        total = C.c_int64()
+        _check(self.lib, self.lib.sts_run_batch(self.h, B, ptrs, n.ctypes.data, sidv.ctypes.data, lsv.ctypes.data,
+                                                n_out.ctypes.data, C.byref(total)))
+        self._total = int(total.value)
+        self._n_out = n_out
+        return n_out
+
+    def pcm_host(self) -> np.ndarray:
+        out = np.empty(self._total, np.int16)
+        _check(self.lib, self.lib.sts_copy_pcm_host(self.h, out.ctypes.data, out.size))
+        return out
+
+    def pcm_to_device_ptr(self, ptr: int, capacity: int) -> None:
+        _check(self.lib, self.lib.sts_copy_pcm_device(self.h, C.c_void_p(ptr), capacity))
+
+    def infer_batch(self, ids, sid=None, length_scale=None) -> List[np.ndarray]:
+        n_out = self.run_batch(ids, sid, length_scale)
+        flat = self.pcm_host()
+        offs = np.concatenate([[0], np.cumsum(n_out)])
+        return [flat[offs[b]:offs[b + 1]].copy() for b in range(len(n_out))]
+
+    # -- parity / diagnostics ---------------------------------------------------------------
+    def set_forced_durations(self, dur: Optional[Sequence[int]]):
+        if dur is None:
+            _check(self.lib, self.lib.sts_set_forced_durations(self.h, None, 0))
+            return
+        d = np.ascontiguousarray(dur, dtype=np.int32)
+        _check(self.lib, self.lib.sts_set_forced_durations(self.h, d.ctypes.data, d.size))
+
+    def set_record_taps(self, on: bool):
+        _check(self.lib, self.lib.sts_set_record_taps(self.h, 1 if on else 0))
+
+    def set_conv_mode(self, mode: int):
+        _check(self.lib, self.lib.sts_set_conv_mode(self.h, mode))
+
+    def set_profiling(self, on: bool):
+        _check(self.lib, self.lib.sts_set_profiling(self.h, 1 if on else 0))
+
+    def profile(self) -> dict:
+        p = Profile()
+        _check(self.lib, self.lib.sts_get_profile(self.h, C.byref(p)))
+        return p.as_dict()
+
+    def tap(self, name: str) -> np.ndarray:
+        ptr = C.POINTER(C.c_float)()
+        ch, ln = C.c_int32(), C.c_int64()
+        _check(self.lib, self.lib.sts_get_tap(self.h, name.encode(), C.byref(ptr), C.byref(ch), C.byref(ln)))
+        a = np.ctypeslib.as_array(ptr, shape=(ch.value, ln.value)).copy()
+        self.lib.sts_free(ptr)
+        return a
+
+    def durations(self, total_phonemes: int) -> np.ndarray:
+        d = np.zeros(total_phonemes, np.int32)
+        _check(self.lib, self.lib.sts_get_durations(self.h, d.ctypes.data, d.size))
+        return d
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.sts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def debug_conv1d(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], pad: int, dil: int = 1,
+                 stride_transposed: int = 0, depthwise: bool = False, in_slope: float = 0.0, in_act: int = 0,
+                 mode: int = 0, device: int = 0) -> np.ndarray:
+    """One conv through the engine's kernels.  x: [Cin, L]; w: [Cout, k, Cin] (reference layout)."""
+    lib = load_library()
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    cout, k = w.shape[0], w.shape[1]
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    y = C.POINTER(C.c_float)()
+    lout = C.c_int32()
+    _check(lib, lib.sts_debug_conv1d(device, x.ctypes.data, x.shape[0], x.shape[1], w.ctypes.data,
+                                     None if b is None else b.ctypes.data, cout, k, pad, dil, stride_transposed,
+                                     1 if depthwise else 0, in_slope, in_act, mode, C.byref(y), C.byref(lout)))
+    out = np.ctypeslib.as_array(y, shape=(cout, lout.value)).copy()
+    lib.sts_free(y)
+    return out
