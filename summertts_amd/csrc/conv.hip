@@ -146,18 +146,54 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
                 dst[p][i] = mvalid[i] ? wp[(size_t)(2 * p) * a.Cout_pad + i * 32] : 0.f;
     };
 
+    // ---- input staging: every thread owns RI columns of the window for all CK rows of a chunk.
+    // The (column -> source index, validity) map does not depend on the chunk, so it is computed
+    // once; the loads of a whole chunk are issued back to back into registers (no load->store
+    // serialisation) and the NEXT chunk's loads are in flight while the current chunk's MFMAs issue.
+    constexpr int RI = (NT + MAX_HALO + NTHR - 1) / NTHR;
+    int xsrc[RI];
+    bool xval[RI];
+#pragma unroll
+    for (int i = 0; i < RI; i++) {
+        const int col = tid + i * NTHR;
+        const int pos = win0 + col;
+        bool v = col < W && pos >= 0 && pos < in_len;
+        int src = pos;
+        if (a.in_reflect) { src = pos - 1; if (src < 0) { src = 1; v = v && orig_len > 1; } }
+        xval[i] = v;
+        xsrc[i] = v ? src : 0;
+    }
+    float xr[CK][RI];
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < CK; r++) {
+            const int ci = c * CK + r;
+            const bool cv = ci < a.Cin;
+            const float* xrow = a.x + (size_t)(cv ? ci : 0) * a.x_ld + in_base;
+#pragma unroll
+            for (int i = 0; i < RI; i++) {
+                float v = xrow[xsrc[i]];
+                v = (cv && xval[i]) ? v : 0.f;
+                if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
+                xr[r][i] = v;
+            }
+        }
+    };
+
     load_a(0, a_cur);
+    load_x(0);
     int s = 0;
     for (int c = 0; c < nchunk; c++) {
         __syncthreads();   // previous chunk's readers are done with the LDS tile
-        for (int r = 0; r < CK; r++) {
-            const int ci = c * CK + r;
-            const float* xrow = a.x + (size_t)ci * a.x_ld + in_base;
-            const bool cvalid = ci < a.Cin;
-            for (int col = tid; col < W; col += NTHR)
-                smem[r * ldsw + col] = cvalid ? load_in(a, xrow, win0 + col, in_len, orig_len) : 0.f;
-        }
+#pragma unroll
+        for (int r = 0; r < CK; r++)
+#pragma unroll
+            for (int i = 0; i < RI; i++) {
+                const int col = tid + i * NTHR;
+                if (col < W) smem[r * ldsw + col] = xr[r][i];
+            }
         __syncthreads();
+        if (c + 1 < nchunk) load_x(c + 1);
         for (int j = 0; j < a.ntap; j++, s++) {
             if (s + 1 < nsteps) load_a(s + 1, a_nxt);
             const int bcol0 = wn * NW * 32 + l31 + j * a.tap_step + a.tap_off - lo;

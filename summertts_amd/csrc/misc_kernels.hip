@@ -36,24 +36,38 @@ void embed(const int* ids, const float* emb, int vocab, int H, float scale, floa
 // LayerNorm over channels per time step (/root/reference/src/nn_op/nn_layer_norm.cpp:65-86):
 // var = sum(x^2)/C - mean^2, eps 1e-5 added in double.  Fused: input add, relu before, gelu after,
 // residual add after.
-__global__ __launch_bounds__(128) void layer_norm_kernel(LnArgs a) {
+// Workgroup = 32 time steps x 8 channel groups: loads coalesce along time (128-B rows), the channel
+// sum is split 8 ways and combined through LDS.
+__global__ __launch_bounds__(256) void layer_norm_kernel(LnArgs a) {
+    __shared__ float rs[8][33], rq[8][33];
     const int b = blockIdx.y;
     const int len = seg_len(a.seg, b);
-    const int pos = blockIdx.x * 128 + threadIdx.x;
-    if (pos >= len) return;
-    const size_t p = (size_t)seg_start(a.seg, b) + pos;
+    const int tx = threadIdx.x & 31, cy = threadIdx.x >> 5;
+    const int pos = blockIdx.x * 32 + tx;
+    const bool live = pos < len;
+    const size_t p = (size_t)seg_start(a.seg, b) + (live ? pos : 0);
     float s = 0.f, sq = 0.f;
-    for (int c = 0; c < a.C; c++) {
-        float v = a.a[(size_t)c * a.a_ld + p];
-        if (a.b) v += a.b[(size_t)c * a.b_ld + p];
-        if (a.pre_relu && v < 0.f) v = 0.f;
-        s += v; sq += v * v;
+    if (live) {
+#pragma unroll 4
+        for (int c = cy; c < a.C; c += 8) {
+            float v = a.a[(size_t)c * a.a_ld + p];
+            if (a.b) v += a.b[(size_t)c * a.b_ld + p];
+            if (a.pre_relu && v < 0.f) v = 0.f;
+            s += v; sq += v * v;
+        }
     }
+    rs[cy][tx] = s; rq[cy][tx] = sq;
+    __syncthreads();
+    if (!live) return;
+    s = 0.f; sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { s += rs[k][tx]; sq += rq[k][tx]; }
     const float mean = s / (float)a.C;
     const float scale = (float)(1. / (float)a.C);
     const float var = sq * scale - mean * mean;
     const float den = (float)sqrt((double)var + 1e-05);
-    for (int c = 0; c < a.C; c++) {
+#pragma unroll 4
+    for (int c = cy; c < a.C; c += 8) {
         float v = a.a[(size_t)c * a.a_ld + p];
         if (a.b) v += a.b[(size_t)c * a.b_ld + p];
         if (a.pre_relu && v < 0.f) v = 0.f;
@@ -65,7 +79,7 @@ __global__ __launch_bounds__(128) void layer_norm_kernel(LnArgs a) {
 }
 void layer_norm(const LnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((a.max_len + 127) / 128, a.B), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((a.max_len + 31) / 32, a.B), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,20 +340,23 @@ void durations(const float* r0, int sdp, float ea_m, float ea_logs, const float*
 // length regulator: frame f of utterance b copies phoneme i with cum[i-1] <= f < cum[i]
 __global__ __launch_bounds__(256) void expand_frames_kernel(const float* m, long m_ld, const int* cum, SegView segT,
                                                             SegView segF, int C, float* z, long z_ld) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.z;
     const int F = seg_len(segF, b), T = seg_len(segT, b);
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
     const size_t tb = (size_t)seg_start(segT, b), fb = (size_t)seg_start(segF, b);
     int lo = 0, hi = T;   // first i with cum[i] > f
     while (lo < hi) { int mid = (lo + hi) >> 1; if (cum[tb + mid] > f) hi = mid; else lo = mid + 1; }
-    if (lo >= T) { for (int c = 0; c < C; c++) z[(size_t)c * z_ld + fb + f] = 0.f; return; }
-    for (int c = 0; c < C; c++) z[(size_t)c * z_ld + fb + f] = m[(size_t)c * m_ld + tb + lo];
+    const int c0 = blockIdx.y * 16, c1 = c0 + 16 < C ? c0 + 16 : C;
+    if (lo >= T) { for (int c = c0; c < c1; c++) z[(size_t)c * z_ld + fb + f] = 0.f; return; }
+#pragma unroll 4
+    for (int c = c0; c < c1; c++) z[(size_t)c * z_ld + fb + f] = m[(size_t)c * m_ld + tb + lo];
 }
 void expand_frames(const float* m, long m_ld, const int* cum, SegView segT, SegView segF, int C, float* z, long z_ld,
                    int B, int max_frames, hipStream_t st) {
     if (B <= 0 || max_frames <= 0) return;
-    hipLaunchKernelGGL(expand_frames_kernel, dim3((max_frames + 255) / 256, B), dim3(256), 0, st, m, m_ld, cum, segT, segF, C, z, z_ld);
+    hipLaunchKernelGGL(expand_frames_kernel, dim3((max_frames + 255) / 256, (C + 15) / 16, B), dim3(256), 0, st, m, m_ld, cum,
+                       segT, segF, C, z, z_ld);
 }
 
 // ---------------------------------------------------------------------------------------------

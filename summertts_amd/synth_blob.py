@@ -99,7 +99,7 @@ class ModelCfg:
 def full_cfg(kind: str) -> ModelCfg:
     """Upstream-default sized configurations (dims marked as assumed)."""
     if kind == "hifigan_sdp":           # VITS: HiFi-GAN decoder + stochastic duration predictor
-        return ModelCfg()
+        return ModelCfg(dur_bias=2.4)   # calibrated so that F/T ~ 5.5 frames per phoneme (SURVEY.md 8d, C2)
     if kind == "mbb_fix":               # MB-iSTFT-VITS (PQMF) + deterministic duration predictor
         return ModelCfg(dur_type=DUR_FIX, dec_type=DEC_MBB, up_rates=(4, 4), up_k=(16, 16))
     if kind == "ms_fix":                # MS-iSTFT-VITS (learned synthesis filter)
@@ -107,7 +107,7 @@ def full_cfg(kind: str) -> ModelCfg:
     if kind == "istft_fix":
         return ModelCfg(dur_type=DUR_FIX, dec_type=DEC_ISTFT, up_rates=(8, 8), up_k=(16, 16))
     if kind == "ms_hifigan_sdp":        # multi-speaker (aishell3-like)
-        return ModelCfg(is_ms=1, spk_num=174, gin=256)
+        return ModelCfg(is_ms=1, spk_num=174, gin=256, dur_bias=1.4)
     raise ValueError(kind)
 
 

@@ -1,0 +1,173 @@
+"""GPU suite (MI355X): the HIP path against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import (TAP_MAXABS_TOL, assert_pcm_close, assert_wave_close, golden_files, load_golden)
+from oracle import pyref
+from summertts_amd import engine, synth_blob as sb
+
+pytestmark = pytest.mark.gpu
+
+TINY = ["hifigan_sdp", "hifigan_fix", "mbb_fix", "ms_sdp", "istft_fix", "ms_hifigan_sdp", "ms_hifigan_fix", "odd"]
+
+CONV_CASES = [  # Cin, Cout, k, pad, dil, L, stride_transposed, depthwise
+    (64, 64, 3, 1, 1, 300, 0, False), (32, 32, 11, 25, 5, 700, 0, False), (96, 192, 1, 0, 1, 77, 0, False),
+    (64, 128, 5, 2, 1, 129, 0, False), (48, 40, 7, 3, 1, 200, 0, False), (20, 24, 3, 3, 3, 50, 0, False),
+    (64, 32, 8, 2, 1, 100, 4, False), (128, 64, 16, 4, 1, 65, 8, False), (24, 12, 7, 2, 1, 33, 3, False),
+    (16, 16, 3, 9, 9, 120, 0, True), (64, 72, 7, 3, 1, 500, 0, False), (256, 256, 3, 1, 1, 1000, 0, False),
+    (32, 1, 7, 3, 1, 1000, 0, False), (4, 1, 63, 31, 1, 400, 0, False), (192, 384, 5, 2, 1, 31, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=str)
+def test_conv_kernels_against_torch_fp32(case):
+    import torch
+    import torch.nn.functional as F
+    ci, co, k, pad, dil, L, st, dw = case
+    rng = np.random.default_rng(ci * 131 + co)
+    x = rng.standard_normal((ci, L)).astype(np.float32)
+    w = (rng.standard_normal((co, k, 1 if dw else ci)) / np.sqrt(k * (1 if dw else ci))).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    xt = torch.from_numpy(x)[None]
+    if st:
+        ref = F.conv_transpose1d(xt, torch.from_numpy(w).permute(2, 0, 1).contiguous(), torch.from_numpy(b), stride=st, padding=pad)[0].numpy()
+    elif dw:
+        ref = F.conv1d(xt, torch.from_numpy(w).permute(0, 2, 1).contiguous(), torch.from_numpy(b), padding=pad, dilation=dil, groups=ci)[0].numpy()
+    else:
+        ref = F.conv1d(xt, torch.from_numpy(w).permute(0, 2, 1).contiguous(), torch.from_numpy(b), padding=pad, dilation=dil)[0].numpy()
+    mfma_ok = not dw and ci >= 32 and co >= 32
+    modes = [1] + ([0, 2, 3, 4, 5, 6, 7] if mfma_ok else [0])
+    outs = {}
+    for mode in modes:
+        y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=mode)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() <= 2e-5, (case, mode, np.abs(y - ref).max())   # fp32, K <= 2816 terms
+        outs[mode] = y
+    if mfma_ok:   # every matrix-core tile shape walks K in the same order: bit-identical results
+        for mode in (2, 3, 4, 5, 6, 7):
+            assert np.array_equal(outs[mode], outs[0]), (case, mode)
+    # fused input leaky-relu
+    y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=0)
+    y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=0)
+    assert np.array_equal(y, y1)
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1])
+def test_hip_matches_reference_golden(path):
+    g, cfg, blob = load_golden(path)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    n = syn.run_batch([g["ids"]], [int(g["sid"])], [float(g["length_scale"])])
+    dur = syn.durations(len(g["ids"]))
+    assert (dur == g["durations"]).all(), "durations differ from the reference"
+    assert_wave_close(syn.tap("wave")[0], g["wave"], "hip vs reference golden")
+    assert_pcm_close(syn.pcm_host(), g["pcm"], "hip vs reference golden")
+    for k in ("m", "z", "logw"):
+        assert np.abs(syn.tap(k) - g[k]).max() <= TAP_MAXABS_TOL, k
+    assert int(n[0]) == g["pcm"].size
+    syn.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "generic"])
+@pytest.mark.parametrize("kind", TINY)
+def test_hip_matches_oracle_all_stages(kind, mode):
+    cfg = sb.tiny_cfg(kind)
+    blob = sb.make_blob(cfg, 4321)
+    ids = sb.synthetic_ids(29, cfg.vocab, salt=3)
+    o = pyref.PortModel(blob).infer_ids(ids, 1, 1.1, taps=True)
+    syn = engine.Synthesizer(blob)
+    assert syn.info.blob_floats_consumed == blob.size
+    syn.set_conv_mode(mode)
+    syn.set_record_taps(True)
+    syn.run_batch([ids], [1], [1.1])                       # free-running durations
+    assert (syn.durations(len(ids)) == o["durations"]).all()
+    for k in ("x_enc", "m", "logw", "z_p", "z"):
+        assert np.abs(syn.tap(k) - o[k]).max() <= TAP_MAXABS_TOL, k
+    assert_wave_close(syn.tap("wave")[0], o["wave"], kind)
+    assert_pcm_close(syn.pcm_host(), o["pcm"], kind)
+    syn.close()
+
+
+@pytest.mark.parametrize("kind", ["hifigan_sdp", "mbb_fix", "ms_hifigan_fix", "ms_sdp"])
+def test_batch_equals_single_utterances_bit_exact(kind):
+    cfg = sb.tiny_cfg(kind)
+    blob = sb.make_blob(cfg, 11)
+    syn = engine.Synthesizer(blob)
+    lens = [9, 31, 5, 17, 1, 24]
+    ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate(lens)]
+    sid = [i % syn.get_speaker_num() for i in range(len(lens))]
+    ls = [1.0, 0.9, 1.2, 1.0, 1.1, 1.05]
+    batch = syn.infer_batch(ids, sid, ls)
+    dur_b = syn.durations(sum(lens))
+    off = 0
+    for i in range(len(lens)):
+        one = syn.infer_ids(ids[i], sid[i], ls[i])
+        assert np.array_equal(one, batch[i]), (kind, i)
+        assert np.array_equal(syn.durations(lens[i]), dur_b[off:off + lens[i]])
+        off += lens[i]
+    syn.close()
+
+
+def test_forced_durations_edge_cases_and_errors():
+    cfg = sb.tiny_cfg("hifigan_fix")
+    blob = sb.make_blob(cfg, 3)
+    port = pyref.PortModel(blob)
+    syn = engine.Synthesizer(blob)
+    ids = sb.synthetic_ids(7, cfg.vocab)
+    for fd in ([1, 0, 3, 2, 0, 1, 4], [0] * 7, [50, 1, 1, 1, 1, 1, 1]):
+        o = port.infer_ids(ids, 0, 1.0, forced_dur=fd)
+        syn.set_forced_durations(fd)
+        assert_pcm_close(syn.infer_ids(ids, 0, 1.0), o["pcm"], str(fd))
+    for T in (1, 2, 4):      # shorter than the attention window + 1
+        i2 = sb.synthetic_ids(T, cfg.vocab)
+        assert_pcm_close(syn.infer_ids(i2, 0, 1.0), port.infer_ids(i2, 0, 1.0)["pcm"], f"T={T}")
+    with pytest.raises(engine.StsError):
+        syn.infer_ids([0, cfg.vocab], 0, 1.0)              # id outside the vocabulary
+    with pytest.raises(engine.StsError):
+        syn.infer_ids([], 0, 1.0)
+    syn.close()
+    # out-of-range speaker id -> 0 (SynthesizerTrn.cpp:366-369)
+    cfg = sb.tiny_cfg("ms_hifigan_fix")
+    syn = engine.Synthesizer(sb.make_blob(cfg, 3))
+    assert syn.get_speaker_num() == cfg.spk_num
+    a = syn.infer_ids(sb.synthetic_ids(8, cfg.vocab), 0, 1.0)
+    b = syn.infer_ids(sb.synthetic_ids(8, cfg.vocab), 99, 1.0)
+    c = syn.infer_ids(sb.synthetic_ids(8, cfg.vocab), 1, 1.0)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    syn.close()
+
+
+@pytest.mark.parametrize("kind", ["hifigan_sdp", "mbb_fix"])
+def test_full_size_properties(kind):
+    """BASELINE.json's full-size model (synthetic weights): size-independent properties + a bounded
+    comparison with the oracle (the real reference where oracle/_ref travelled, else the restatement)."""
+    cfg = sb.full_cfg(kind)
+    blob = sb.make_blob(cfg, 1234)
+    syn = engine.Synthesizer(blob)
+    ids128 = sb.synthetic_ids(128, cfg.vocab)
+    a = syn.infer_ids(ids128, 0, 1.0)
+    dur = syn.durations(128)
+    assert a.size == int(dur.sum()) * cfg.hop_total and a.size > 128 * cfg.hop_total
+    assert np.array_equal(a, syn.infer_ids(ids128, 0, 1.0)), "not deterministic"
+    slow = syn.infer_ids(ids128, 0, 1.5)
+    assert (syn.durations(128) >= dur).all() and slow.size > a.size   # lengthScale only stretches
+    # batch invariance at full size
+    ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate((40, 128, 77))]
+    batch = syn.infer_batch(ids)
+    assert np.array_equal(batch[1], a)
+    assert np.array_equal(batch[0], syn.infer_ids(ids[0]))
+    # generic VALU kernels and matrix-core kernels agree to fp32 noise
+    syn.set_conv_mode(1)
+    gen = syn.infer_ids(ids[0])
+    syn.set_conv_mode(0)
+    assert_pcm_close(gen, batch[0], "generic vs mfma")
+    # bounded oracle comparison (T=12 keeps the CPU side to seconds)
+    small = sb.synthetic_ids(12, cfg.vocab, salt=9)
+    model = pyref.RefModel(blob) if pyref.have_ref() else pyref.PortModel(blob)
+    o = model.infer_ids(small, 0, 1.0)
+    syn.set_record_taps(True)
+    syn.run_batch([small])
+    assert (syn.durations(12) == o["durations"]).all()
+    assert_wave_close(syn.tap("wave")[0], o["wave"], "full-size vs oracle")
+    assert_pcm_close(syn.pcm_host(), o["pcm"], "full-size vs oracle")
+    syn.close()

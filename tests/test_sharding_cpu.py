@@ -1,0 +1,56 @@
+"""CPU suite: utterance sharding and the variable-length PCM gather (gloo, world_size 2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from summertts_amd import sharding
+
+
+def test_shard_utterances_is_a_balanced_partition():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(64, 257, size=256).tolist()
+    for world in (1, 2, 4, 8):
+        shards = sharding.shard_utterances(lens, world)
+        assert sorted(i for s in shards for i in s) == list(range(256))
+        loads = [sum(lens[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(lens)
+        assert all(s == sorted(s) for s in shards)
+    assert sharding.shard_utterances([5, 5, 5], 4) == [[0], [1], [2], []]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = [100, 7, 300, 41, 13]
+    shards = sharding.shard_utterances(lens, world)
+    mine = shards[rank]
+    max_utts = max(len(s) for s in shards)
+    pcs = [np.full(lens[u] * 3, u + 1, np.int16) + np.arange(lens[u] * 3, dtype=np.int16) for u in mine]
+    local = torch.from_numpy(np.concatenate(pcs)) if pcs else torch.zeros(0, dtype=torch.int16)
+    res = sharding.gather_variable(local, [p.size for p in pcs], dist, torch, rank, world, max_utts)
+    if rank == 0:
+        ok = True
+        for r in range(world):
+            for k, u in enumerate(shards[r]):
+                exp = np.full(lens[u] * 3, u + 1, np.int16) + np.arange(lens[u] * 3, dtype=np.int16)
+                ok = ok and np.array_equal(res[r][k], exp)
+        q.put(ok)
+    dist.destroy_process_group()
+
+
+def test_gather_variable_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
