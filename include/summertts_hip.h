@@ -85,7 +85,8 @@ int sts_set_record_taps(sts_engine* e, int enable);
 int sts_get_tap(sts_engine* e, const char* name, float** data, int32_t* channels, int64_t* length);
 /*   durations of the last run, packed (sum of n entries) */
 int sts_get_durations(sts_engine* e, int32_t* dur, int64_t capacity);
-/*   conv dispatch: 0 = automatic, 1 = force the generic VALU kernel everywhere, 2.. = force MFMA tile (idx-2) */
+/*   conv dispatch: 0 = automatic, 1 = force the generic VALU kernel everywhere, 2..7 = force LDS-staged
+ *   matrix-core tile (idx-2), 8 / 9 = force the split-K matrix-core kernel (32 / 64 columns per workgroup) */
 int sts_set_conv_mode(sts_engine* e, int mode);
 
 /* Per-stage device timing of the last run, measured with HIP events on the engine's own stream. */
@@ -106,6 +107,13 @@ int sts_get_profile(const sts_engine* e, sts_profile* p);
 int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias,
                      int32_t Cout, int32_t k, int32_t pad, int32_t dil, int32_t stride_transposed,
                      int32_t depthwise, float in_slope, int32_t in_act, int mode, float** y, int32_t* Lout);
+
+/* Same conv, additionally timed: `iters` back-to-back launches between two HIP events; *ms_out = mean
+ * milliseconds per launch (kernel micro-benchmarks, tools/conv_bench.py). */
+int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias,
+                           int32_t Cout, int32_t k, int32_t pad, int32_t dil, int32_t stride_transposed,
+                           int32_t depthwise, float in_slope, int32_t in_act, int mode, float** y, int32_t* Lout,
+                           int32_t iters, float* ms_out);
 
 void sts_free(void* p);
 const char* sts_last_error(void);

@@ -146,6 +146,13 @@ int sts_get_durations(sts_engine* e, int32_t* dur, int64_t cap) {
 int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias, int32_t Cout,
                      int32_t k, int32_t pad, int32_t dil, int32_t stride_t, int32_t depthwise, float in_slope, int32_t in_act,
                      int mode, float** y_out, int32_t* Lout_out) {
+    return sts_debug_conv1d_bench(device, x, Cin, L, w, bias, Cout, k, pad, dil, stride_t, depthwise, in_slope, in_act, mode,
+                                  y_out, Lout_out, 0, nullptr);
+}
+
+int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias, int32_t Cout,
+                           int32_t k, int32_t pad, int32_t dil, int32_t stride_t, int32_t depthwise, float in_slope,
+                           int32_t in_act, int mode, float** y_out, int32_t* Lout_out, int32_t iters, float* ms_out) {
     if (!x || !w || !y_out || !Lout_out || Cin <= 0 || Cout <= 0 || L <= 0 || k <= 0) return set_err(STS_EINVAL, "bad conv arguments");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return set_err(STS_EDEVICE, "no HIP device visible (no CPU fallback)");
@@ -174,7 +181,7 @@ int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const f
     if (bias) memcpy(bp.data(), bias, sizeof(float) * Cout);
     float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr; int* dseg = nullptr;
     int seg[2] = {0, 1};
-    bool ok = hipMalloc((void**)&dx, (size_t)Cin * L * 4) == hipSuccess && hipMalloc((void**)&dw, wn * 4) == hipSuccess &&
+    bool ok = hipMalloc((void**)&dx, (size_t)Cin * L * 4) == hipSuccess && hipMalloc((void**)&dw, (wn + 1024) * 4) == hipSuccess &&
               hipMalloc((void**)&db, (size_t)Cout_pad * 4) == hipSuccess && hipMalloc((void**)&dy, (size_t)Cout * Lout * 4) == hipSuccess &&
               hipMalloc((void**)&dseg, 8) == hipSuccess;
     int rc = STS_OK;
@@ -195,9 +202,25 @@ int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const f
         a.in_act = in_act; a.in_slope = in_slope; a.epi = EPI_STORE;
         // segment lengths in base units: in = L, out = Lout -> two views over the same {off=0,len=1} table
         a.in_seg = SegView{dseg, dseg + 1, L, 0}; a.out_seg = SegView{dseg, dseg + 1, Lout, 0}; a.B = 1;
-        if (mode != 1 && conv_mfma_eligible(a)) conv_mfma(a, nullptr, mode >= 2 ? mode - 2 : -1);
-        else if (mode >= 2) rc = set_err(STS_EINVAL, "shape not eligible for the matrix-core kernel");
-        else conv_generic(a, nullptr);
+        auto launch = [&]() {
+            if (mode != 1 && conv_mfma_eligible(a)) conv_mfma(a, nullptr, mode >= 2 ? mode - 2 : -1);
+            else conv_generic(a, nullptr);
+        };
+        if (mode >= 2 && !conv_mfma_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the matrix-core kernel");
+        else launch();
+        if (rc == STS_OK && iters > 0 && ms_out) {   // steady-state timing of the same launch (HIP events, null stream)
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(e0, nullptr);
+            for (int it = 0; it < iters; it++) launch();
+            (void)hipEventRecord(e1, nullptr);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            *ms_out = ms / (float)iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
         if (rc == STS_OK && (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)) rc = set_err(STS_EDEVICE, "conv kernel failed");
         if (rc == STS_OK) {
             float* y = (float*)malloc((size_t)Cout * Lout * 4);

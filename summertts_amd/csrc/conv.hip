@@ -37,6 +37,17 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// Raw buffer descriptor (SRSRC): the hardware range-checks every access against num_records and
+// returns 0 for anything outside -- zero padding without a single branch or select in the loop.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+constexpr unsigned kOOB = 0x7FFFFFF0u;   // byte offset that is out of range for every descriptor
+
 __device__ __forceinline__ int seg_start(const SegView& s, int b) { return s.off[b] * s.scale + b * s.extra; }
 __device__ __forceinline__ int seg_len(const SegView& s, int b) { return s.len[b] * s.scale + s.extra; }
 
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
     const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
     const int lo = first < last ? first : last, hi = first < last ? last : first;
     const int W = NT + (hi - lo);      // staged window width (<= NT + MAX_HALO)
-    const int ldsw = W;
+    constexpr int ldsw = ((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR;   // every thread stores unconditionally
     const int win0 = n0 + lo;
 
     const float* w = a.w + (size_t)phase * a.ntap * a.Cin_pad * a.Cout_pad;
@@ -133,17 +144,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
 
     const int nchunk = a.Cin_pad / CK;
     const int nsteps = nchunk * a.ntap;
-    float a_cur[CK / 2][MW], a_nxt[CK / 2][MW];
 
-    // A fragment of step s = chunk*ntap + tap : lane holds W[tap][chunk*CK + 2p + half][mbase + mw*32 + l31]
-    auto load_a = [&](int s, float (&dst)[CK / 2][MW]) {
-        const int c = s / a.ntap, j = s - c * a.ntap;
+    // A fragment of step s = chunk*ntap + tap : lane holds W[tap][chunk*CK + 2p + half][mbase + mw*32 + l31].
+    // Row tiles beyond Cout_pad read whatever follows in the (slack-padded) weight store: those
+    // accumulator rows are never stored, so the loop carries no per-lane predicate at all.
+    auto load_a = [&](int c, int j, float (&dst)[CK / 2][MW]) {
         const float* wp = w + ((size_t)j * a.Cin_pad + (size_t)c * CK + half) * a.Cout_pad + mbase + l31;
 #pragma unroll
         for (int p = 0; p < CK / 2; p++)
 #pragma unroll
-            for (int i = 0; i < MW; i++)
-                dst[p][i] = mvalid[i] ? wp[(size_t)(2 * p) * a.Cout_pad + i * 32] : 0.f;
+            for (int i = 0; i < MW; i++) dst[p][i] = wp[(size_t)(2 * p) * a.Cout_pad + i * 32];
+    };
+    // B fragment of tap j: the staged LDS rows read at the tap's column shift
+    auto load_b = [&](int j, float (&dst)[CK / 2][NW]) {
+        const int bcol0 = wn * NW * 32 + l31 + j * a.tap_step + a.tap_off - lo;
+#pragma unroll
+        for (int p = 0; p < CK / 2; p++)
+#pragma unroll
+            for (int q = 0; q < NW; q++) dst[p][q] = smem[(2 * p + half) * ldsw + bcol0 + q * 32];
     };
 
     // ---- input staging: every thread owns RI columns of the window for all CK rows of a chunk.
@@ -151,8 +169,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
     // once; the loads of a whole chunk are issued back to back into registers (no load->store
     // serialisation) and the NEXT chunk's loads are in flight while the current chunk's MFMAs issue.
     constexpr int RI = (NT + MAX_HALO + NTHR - 1) / NTHR;
-    int xsrc[RI];
-    bool xval[RI];
+    unsigned xoff[RI];
 #pragma unroll
     for (int i = 0; i < RI; i++) {
         const int col = tid + i * NTHR;
@@ -160,62 +177,60 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
         bool v = col < W && pos >= 0 && pos < in_len;
         int src = pos;
         if (a.in_reflect) { src = pos - 1; if (src < 0) { src = 1; v = v && orig_len > 1; } }
-        xval[i] = v;
-        xsrc[i] = v ? src : 0;
+        xoff[i] = v ? (unsigned)src * 4u : kOOB;
     }
     float xr[CK][RI];
     auto load_x = [&](int c) {
 #pragma unroll
         for (int r = 0; r < CK; r++) {
             const int ci = c * CK + r;
-            const bool cv = ci < a.Cin;
-            const float* xrow = a.x + (size_t)(cv ? ci : 0) * a.x_ld + in_base;
+            const rsrc_t rs = make_rsrc(a.x + (size_t)ci * a.x_ld + in_base, ci < a.Cin ? (unsigned)orig_len * 4u : 0u);
 #pragma unroll
-            for (int i = 0; i < RI; i++) {
-                float v = xrow[xsrc[i]];
-                v = (cv && xval[i]) ? v : 0.f;
-                if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
-                xr[r][i] = v;
-            }
+            for (int i = 0; i < RI; i++) xr[r][i] = buf_load(rs, xoff[i]);   // raw: activation is applied at store time
         }
     };
-
-    load_a(0, a_cur);
-    load_x(0);
-    int s = 0;
-    for (int c = 0; c < nchunk; c++) {
+    auto stage_chunk = [&](int c) {
         __syncthreads();   // previous chunk's readers are done with the LDS tile
 #pragma unroll
         for (int r = 0; r < CK; r++)
 #pragma unroll
             for (int i = 0; i < RI; i++) {
-                const int col = tid + i * NTHR;
-                if (col < W) smem[r * ldsw + col] = xr[r][i];
+                float v = xr[r][i];
+                if (a.in_act) v = v < 0.f ? v * a.in_slope : v;   // fused input leaky-relu / relu
+                smem[r * ldsw + tid + i * NTHR] = v;
             }
         __syncthreads();
         if (c + 1 < nchunk) load_x(c + 1);
-        for (int j = 0; j < a.ntap; j++, s++) {
-            if (s + 1 < nsteps) load_a(s + 1, a_nxt);
-            const int bcol0 = wn * NW * 32 + l31 + j * a.tap_step + a.tap_off - lo;
-#pragma unroll
-            for (int p = 0; p < CK / 2; p++) {
-                float bv[NW];
-#pragma unroll
-                for (int q = 0; q < NW; q++) bv[q] = smem[(2 * p + half) * ldsw + bcol0 + q * 32];
-#pragma unroll
-                for (int i = 0; i < MW; i++) {
-                    if (mvalid[i]) {
-#pragma unroll
-                        for (int q = 0; q < NW; q++)
-                            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[p][i], bv[q], acc[i][q], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < CK / 2; p++)
-#pragma unroll
-                for (int i = 0; i < MW; i++) a_cur[p][i] = a_nxt[p][i];
+    };
+
+    // ---- main loop over steps (chunk, tap), unrolled by two with ping-pong fragment buffers: while
+    // step s issues its MFMAs, the A fragment (global/L2) and the B fragment (LDS) of step s+1 are
+    // already in flight into the other buffer.  No register copies, no waits on the fresh loads.
+    float fa0[CK / 2][MW], fa1[CK / 2][MW], fb0[CK / 2][NW], fb1[CK / 2][NW];
+    int sc = 0, sj = 0;   // chunk / tap of the current step
+    auto do_step = [&](float (&acur)[CK / 2][MW], float (&anxt)[CK / 2][MW], float (&bcur)[CK / 2][NW],
+                       float (&bnxt)[CK / 2][NW], int s) {
+        if (sj == 0) { stage_chunk(sc); load_b(0, bcur); }
+        int nj = sj + 1, nc = sc;
+        if (nj == a.ntap) { nj = 0; nc = sc + 1; }
+        if (s + 1 < nsteps) {
+            load_a(nc, nj, anxt);
+            if (nj != 0) load_b(nj, bnxt);
         }
+#pragma unroll
+        for (int p = 0; p < CK / 2; p++)
+#pragma unroll
+            for (int i = 0; i < MW; i++)
+#pragma unroll
+                for (int q = 0; q < NW; q++)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p][i], bcur[p][q], acc[i][q], 0, 0, 0);
+        sj = nj; sc = nc;
+    };
+    load_x(0);
+    load_a(0, 0, fa0);
+    for (int s = 0; s < nsteps; s += 2) {
+        do_step(fa0, fa1, fb0, fb1, s);
+        if (s + 1 < nsteps) do_step(fa1, fa0, fb1, fb0, s + 1);
     }
 
     // ---- epilogue on the accumulator registers -------------------------------------------------
@@ -266,6 +281,153 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
             }
         });
     });
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-K matrix-core kernel for LATENCY-bound shapes (batch-1 text encoder / flow / duration
+// predictor: N = 128..700 positions, a few dozen output tiles, K up to 2304).  The LDS-staged kernel
+// above would run such a conv on a handful of CUs as one long dependent chain of global-load round
+// trips.  Here every workgroup owns ONE (32*MW) x (32*NW) output tile and its KS waves split the K
+// loop (groups of 8 input channels of one tap, interleaved over the waves); both operands stream
+// straight from L2 into a 3-deep register ring -- no LDS staging, no barrier inside the K loop -- and
+// the KS partial accumulators are summed through LDS once, followed by the same fused epilogues.
+// ------------------------------------------------------------------------------------------------
+template <int MW, int NW>
+__global__ __launch_bounds__(MW * NW <= 1 ? 1024 : (MW * NW <= 2 ? 512 : 256)) void conv_mfma_splitk_kernel(ConvArgs a, int mtiles) {
+    constexpr int G = 4, D = 3, E = MW * NW * 16;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [KS][E][64]
+    const int KS = blockDim.x >> 6;
+    const int b = blockIdx.z;
+    const int orig_len = seg_len(a.in_seg, b);
+    const int in_len = orig_len + (a.in_reflect ? 1 : 0);
+    const int out_len = seg_len(a.out_seg, b);
+    const int n_count = a.transposed ? in_len + a.n_extra : out_len;
+    const int n0 = blockIdx.x * 32 * NW;
+    if (n0 >= n_count) return;
+    const int phase = blockIdx.y / mtiles;
+    const int m0 = (blockIdx.y - phase * mtiles) * 32 * MW;
+    const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const float* w = a.w + (size_t)phase * a.ntap * a.Cin_pad * a.Cout_pad;
+    bool mvalid[MW];
+#pragma unroll
+    for (int i = 0; i < MW; i++) mvalid[i] = (m0 + i * 32) < a.Cout_pad;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; i++)
+#pragma unroll
+        for (int q = 0; q < NW; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][q][r] = 0.f;
+
+    const int gpt = a.Cin_pad / (2 * G);   // groups per tap
+    const int ngroups = a.ntap * gpt;
+    float ra[D][G][MW], rb[D][G][NW];
+
+    // x through ONE raw buffer descriptor based at this utterance's first sample: the two half-waves read
+    // different channels, so the channel row is folded into the per-lane byte offset; padding positions
+    // and padded channels use an out-of-range offset and come back as 0 from the range check.
+    // (the launcher only picks this kernel while Cin_pad * x_ld * 4 fits the 32-bit offset)
+    const rsrc_t xrs = make_rsrc(a.x + in_base, (unsigned)(((size_t)(a.Cin - 1) * a.x_ld + orig_len) * 4));   // < kOOB
+    auto load_group = [&](int g, float (&fa)[G][MW], float (&fb)[G][NW]) {
+        const int j = g / gpt, c0 = (g - j * gpt) * 2 * G;
+        const int shift = j * a.tap_step + a.tap_off;
+        unsigned off[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const int pos = n0 + q * 32 + l31 + shift;
+            bool v = pos >= 0 && pos < in_len;
+            int sidx = pos;
+            if (a.in_reflect) { sidx = pos - 1; if (sidx < 0) { sidx = 1; v = v && orig_len > 1; } }
+            off[q] = v ? (unsigned)sidx * 4u : kOOB;
+        }
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int ci = c0 + 2 * i + half;
+            const unsigned rowoff = ci < a.Cin ? (unsigned)ci * (unsigned)a.x_ld * 4u : kOOB;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const unsigned o = (rowoff == kOOB || off[q] == kOOB) ? kOOB : rowoff + off[q];
+                fb[i][q] = buf_load(xrs, o);   // raw: activation applied when the group is consumed
+            }
+            const float* wp = w + ((size_t)j * a.Cin_pad + ci) * a.Cout_pad + m0 + l31;
+#pragma unroll
+            for (int k = 0; k < MW; k++) fa[i][k] = wp[k * 32];
+        }
+    };
+
+    int gnext = wave;
+#pragma unroll
+    for (int d = 0; d < D; d++) { if (gnext < ngroups) load_group(gnext, ra[d], rb[d]); gnext += KS; }
+    int gcur = wave;
+    while (gcur < ngroups) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (gcur < ngroups) {
+#pragma unroll
+                for (int i = 0; i < G; i++) {
+                    float bq[NW];
+#pragma unroll
+                    for (int q = 0; q < NW; q++) {
+                        float v = rb[d][i][q];
+                        if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
+                        bq[q] = v;
+                    }
+#pragma unroll
+                    for (int k = 0; k < MW; k++)
+#pragma unroll
+                        for (int q = 0; q < NW; q++)
+                            acc[k][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][i][k], bq[q], acc[k][q], 0, 0, 0);
+                }
+                if (gnext < ngroups) load_group(gnext, ra[d], rb[d]);
+            }
+            gnext += KS; gcur += KS;
+        }
+    }
+
+    // ---- combine the KS partial tiles
+    static_for<0, MW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, NW>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                red[((size_t)wave * E + (i * NW + q) * 16 + r) * 64 + lane] = acc[i][q][r];
+            });
+        });
+    });
+    __syncthreads();
+    const int out_off = a.out_off + phase;
+    const bool gate = a.epi == EPI_GATE;
+    const int nelem = gate ? NW * 16 : E;    // gate: the (tanh, sigmoid) tile pair is handled together
+    for (int e = wave; e < nelem; e += KS) {
+        const int i = gate ? 0 : e / (NW * 16);
+        const int q = (e >> 4) % NW, r = e & 15;
+        const int n = n0 + q * 32 + l31;
+        const int pos = n * a.out_stride + out_off;
+        if (n >= n_count || pos < 0 || pos >= out_len) continue;
+        const size_t opos = out_base + (size_t)pos;
+        const int rowp = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = 0.f, v2 = 0.f;
+        for (int k = 0; k < KS; k++) {
+            v += red[((size_t)k * E + (i * NW + q) * 16 + r) * 64 + lane];
+            if (gate) v2 += red[((size_t)k * E + (NW + q) * 16 + r) * 64 + lane];
+        }
+        if (gate) {
+            if (MW < 2 || !mvalid[0]) continue;
+            if (a.bias) { v += a.bias[rowp]; v2 += a.bias[rowp + 32]; }
+            if (a.ubias) { v += a.ubias[(size_t)rowp * a.ubias_ld + b]; v2 += a.ubias[(size_t)(rowp + 32) * a.ubias_ld + b]; }
+            const int ch = (rowp >> 6) * 32 + (rowp & 31);
+            if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(v) * sigmoid_ref(v2);
+        } else {
+            if (rowp >= a.Cout) continue;
+            if (a.bias) v += a.bias[rowp];
+            if (a.ubias) v += a.ubias[(size_t)rowp * a.ubias_ld + b];
+            epi_scalar(a, rowp, opos, v);
+        }
+    }
 }
 
 struct TileCfg { int MW, NW, WM, WN; };
@@ -319,15 +481,47 @@ static void launch_mfma(const ConvArgs& a, int nphase, hipStream_t st) {
     int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
     int halo = first < last ? last - first : first - last;
     dim3 grid((a.max_n + NT - 1) / NT, mt * nphase, a.B);
-    size_t lds = (size_t)CK * (NT + halo) * sizeof(float);
+    constexpr int NTHR = WM * WN * 64;
+    size_t lds = (size_t)CK * (((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR) * sizeof(float);
+    (void)halo;
     hipLaunchKernelGGL((conv_mfma_kernel<MW, NW, WM, WN>), grid, dim3(WM * WN * 64), lds, st, a, mt);
 }
 
+template <int MW, int NW>
+static void launch_splitk(const ConvArgs& a, int nphase, hipStream_t st) {
+    const int mt = (a.Cout_pad + 32 * MW - 1) / (32 * MW);
+    const int nt = (a.max_n + 32 * NW - 1) / (32 * NW);
+    const long steps = (long)a.ntap * (a.Cin_pad / 8);          // groups of 4 channel pairs
+    constexpr int E = MW * NW * 16;
+    const int ks_cap = E <= 16 ? 16 : (E <= 32 ? 8 : 4);        // LDS for the partial tiles <= 64 KiB
+    // enough waves that each one issues >= ~6 groups (24 MFMA rounds), but do not drown the chip
+    int ks = 1;
+    while (ks < ks_cap && steps / (ks * 2) >= 6 && (long)mt * nt * nphase * a.B * ks * 2 <= 4096) ks *= 2;
+    dim3 grid(nt, mt * nphase, a.B);
+    size_t lds = (size_t)ks * E * 64 * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_splitk_kernel<MW, NW>), grid, dim3(ks * 64), lds, st, a, mt);
+}
+
+// mode: -1 automatic; 0..5 force an LDS-staged tile; 6 / 7 force the split-K kernel (NW = 1 / 2)
 void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
     int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
-    if (tile < 0 || tile >= kNumTiles) tile = pick_tile(a, nphase);
-    if (a.epi == EPI_GATE && kTiles[tile].MW != 2) tile = 3;
+    const bool gate = a.epi == EPI_GATE;
+    bool splitk = tile == 6 || tile == 7;
+    int nw = tile == 7 ? 2 : 1;
+    if (tile < 0 || tile > 7) {
+        tile = pick_tile(a, nphase);
+        const TileCfg& t = kTiles[tile];
+        const int MT = 32 * t.MW * t.WM, NT = 32 * t.NW * t.WN;
+        const long blocks = (long)((a.max_n + NT - 1) / NT) * ((a.Cout_pad + MT - 1) / MT) * nphase * a.B;
+        if (blocks < 256 && (double)a.Cin_pad * (double)a.x_ld * 4.0 < 2.0e9) { splitk = true; nw = ((a.max_n + 63) / 64) * ((a.Cout_pad + 31) / 32) * nphase * (long)a.B >= 512 ? 2 : 1; }
+    }
+    if (splitk) {
+        if (gate) { if (nw == 2) launch_splitk<2, 2>(a, nphase, st); else launch_splitk<2, 1>(a, nphase, st); }
+        else { if (nw == 2) launch_splitk<1, 2>(a, nphase, st); else launch_splitk<1, 1>(a, nphase, st); }
+        return;
+    }
+    if (gate && kTiles[tile].MW != 2) tile = 3;
     switch (tile) {
         case 0: launch_mfma<2, 2, 2, 2>(a, nphase, st); break;
         case 1: launch_mfma<2, 2, 1, 4>(a, nphase, st); break;

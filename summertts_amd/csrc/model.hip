@@ -410,6 +410,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
     }
     if (!r.ok) FAIL("blob truncated");
     m.consumed = r.o;
+    { const float* slack; if (!st.alloc(1024, &slack)) FAIL("weight store overflow"); }   // kernels may read one row tile past a tensor
     m.dev_floats = st.used;
     if (hipMemcpy(st.dev, st.host.data(), st.used * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) FAIL("weight upload failed");
     return true;

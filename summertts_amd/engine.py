@@ -77,6 +77,7 @@ def load_library() -> C.CDLL:
     lib.sts_debug_conv1d.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                      C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32)]
+    lib.sts_debug_conv1d_bench.argtypes = lib.sts_debug_conv1d.argtypes + [C.c_int32, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -85,7 +86,7 @@ EXPORTED_SYMBOLS = [
     "sts_create", "sts_destroy", "sts_speaker_num", "sts_get_info", "sts_infer_ids", "sts_infer_ids_batch",
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_profiling",
-    "sts_get_profile", "sts_debug_conv1d", "sts_free", "sts_last_error",
+    "sts_get_profile", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
 ]
 
 
@@ -198,8 +199,9 @@ class Synthesizer:
 
 def debug_conv1d(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], pad: int, dil: int = 1,
                  stride_transposed: int = 0, depthwise: bool = False, in_slope: float = 0.0, in_act: int = 0,
-                 mode: int = 0, device: int = 0) -> np.ndarray:
-    """One conv through the engine's kernels.  x: [Cin, L]; w: [Cout, k, Cin] (reference layout)."""
+                 mode: int = 0, device: int = 0, iters: int = 0):
+    """One conv through the engine's kernels.  x: [Cin, L]; w: [Cout, k, Cin] (reference layout).
+    With iters > 0 returns (y, mean milliseconds per launch)."""
     lib = load_library()
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
@@ -207,9 +209,11 @@ def debug_conv1d(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], pad: 
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     y = C.POINTER(C.c_float)()
     lout = C.c_int32()
-    _check(lib, lib.sts_debug_conv1d(device, x.ctypes.data, x.shape[0], x.shape[1], w.ctypes.data,
-                                     None if b is None else b.ctypes.data, cout, k, pad, dil, stride_transposed,
-                                     1 if depthwise else 0, in_slope, in_act, mode, C.byref(y), C.byref(lout)))
+    ms = C.c_float(0.0)
+    _check(lib, lib.sts_debug_conv1d_bench(device, x.ctypes.data, x.shape[0], x.shape[1], w.ctypes.data,
+                                           None if b is None else b.ctypes.data, cout, k, pad, dil, stride_transposed,
+                                           1 if depthwise else 0, in_slope, in_act, mode, C.byref(y), C.byref(lout),
+                                           iters, C.byref(ms)))
     out = np.ctypeslib.as_array(y, shape=(cout, lout.value)).copy()
     lib.sts_free(y)
-    return out
+    return (out, float(ms.value)) if iters > 0 else out

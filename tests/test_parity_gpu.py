@@ -36,16 +36,16 @@ def test_conv_kernels_against_torch_fp32(case):
     else:
         ref = F.conv1d(xt, torch.from_numpy(w).permute(0, 2, 1).contiguous(), torch.from_numpy(b), padding=pad, dilation=dil)[0].numpy()
     mfma_ok = not dw and ci >= 32 and co >= 32
-    modes = [1] + ([0, 2, 3, 4, 5, 6, 7] if mfma_ok else [0])
+    modes = [1] + ([0, 2, 3, 4, 5, 6, 7, 8, 9] if mfma_ok else [0])
     outs = {}
     for mode in modes:
         y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=mode)
         assert y.shape == ref.shape
         assert np.abs(y - ref).max() <= 2e-5, (case, mode, np.abs(y - ref).max())   # fp32, K <= 2816 terms
         outs[mode] = y
-    if mfma_ok:   # every matrix-core tile shape walks K in the same order: bit-identical results
-        for mode in (2, 3, 4, 5, 6, 7):
-            assert np.array_equal(outs[mode], outs[0]), (case, mode)
+    if mfma_ok:   # every LDS-staged matrix-core tile shape walks K in the same order: bit-identical results
+        for mode in (3, 4, 5, 6, 7):
+            assert np.array_equal(outs[mode], outs[2]), (case, mode)
     # fused input leaky-relu
     y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=0)
     y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=0)
@@ -82,7 +82,10 @@ def test_hip_matches_oracle_all_stages(kind, mode):
     syn.run_batch([ids], [1], [1.1])                       # free-running durations
     assert (syn.durations(len(ids)) == o["durations"]).all()
     for k in ("x_enc", "m", "logw", "z_p", "z"):
-        assert np.abs(syn.tap(k) - o[k]).max() <= TAP_MAXABS_TOL, k
+        # logw: the inverse rational-quadratic spline amplifies fp32 noise by up to 1/min_derivative
+        tol = 1e-3 if k == "logw" else TAP_MAXABS_TOL
+        err = np.abs(syn.tap(k) - o[k]).max()
+        assert err <= tol, (k, err)
     assert_wave_close(syn.tap("wave")[0], o["wave"], kind)
     assert_pcm_close(syn.pcm_host(), o["pcm"], kind)
     syn.close()
@@ -97,6 +100,10 @@ def test_batch_equals_single_utterances_bit_exact(kind):
     ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate(lens)]
     sid = [i % syn.get_speaker_num() for i in range(len(lens))]
     ls = [1.0, 0.9, 1.2, 1.0, 1.1, 1.05]
+    # with the kernel variant pinned, an utterance's samples do not depend on what it is batched with
+    # (same K order per output element); in automatic mode the dispatcher may pick another variant for
+    # another batch geometry, which is fp32-noise different: <= 1 LSB.
+    syn.set_conv_mode(6)
     batch = syn.infer_batch(ids, sid, ls)
     dur_b = syn.durations(sum(lens))
     off = 0
@@ -105,6 +112,10 @@ def test_batch_equals_single_utterances_bit_exact(kind):
         assert np.array_equal(one, batch[i]), (kind, i)
         assert np.array_equal(syn.durations(lens[i]), dur_b[off:off + lens[i]])
         off += lens[i]
+    syn.set_conv_mode(0)
+    auto = syn.infer_batch(ids, sid, ls)
+    for i in range(len(lens)):
+        assert_pcm_close(auto[i], batch[i], f"{kind} auto vs pinned, utterance {i}")
     syn.close()
 
 
@@ -154,8 +165,12 @@ def test_full_size_properties(kind):
     # batch invariance at full size
     ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate((40, 128, 77))]
     batch = syn.infer_batch(ids)
-    assert np.array_equal(batch[1], a)
-    assert np.array_equal(batch[0], syn.infer_ids(ids[0]))
+    assert_pcm_close(batch[1], a, "batched vs single (automatic kernel choice)")
+    syn.set_conv_mode(6)            # pinned kernel variant: bit-exact batch invariance
+    pinned = syn.infer_batch(ids)
+    assert np.array_equal(pinned[0], syn.infer_ids(ids[0]))
+    assert np.array_equal(pinned[2], syn.infer_ids(ids[2]))
+    syn.set_conv_mode(0)
     # generic VALU kernels and matrix-core kernels agree to fp32 noise
     syn.set_conv_mode(1)
     gen = syn.infer_ids(ids[0])
