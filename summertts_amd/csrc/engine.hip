@@ -24,7 +24,12 @@ Engine::~Engine() {
     if (arenaT_.base) (void)hipFree(arenaT_.base);
     if (arenaF_.base) (void)hipFree(arenaF_.base);
     if (pinned_) (void)hipHostFree(pinned_);
-    if (have_events_) for (auto& e : ev_) (void)hipEventDestroy(e);
+    if (have_events_) {
+        for (auto& e : ev_) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(ev_fork_);
+        for (auto& e : ev_join_) (void)hipEventDestroy(e);
+        for (auto& a : aux_) if (a) (void)hipStreamDestroy(a);
+    }
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -37,6 +42,10 @@ int Engine::init(const float* blob, int64_t bytes, int dev) {
     HIPCK(hipSetDevice(dev));
     HIPCK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& e : ev_) HIPCK(hipEventCreate(&e));
+    HIPCK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    for (auto& e : ev_join_) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& a : aux_) HIPCK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    cur_ = stream;
     have_events_ = true;
     if (!blob || bytes < 32) return fail(STS_EMODEL, "model blob too small");
     if (!load_model(blob, bytes / (int64_t)sizeof(float), model)) return fail(STS_EMODEL, "model parse failed: " + model.error);
@@ -99,9 +108,9 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
     if (can_mfma) {
         if (in_mfma_region_) { mfma_flops_ += fl; mfma_launches_++; }
-        conv_mfma(a, stream, conv_mode >= 2 ? conv_mode - 2 : -1);
+        conv_mfma(a, cur_, conv_mode >= 2 ? conv_mode - 2 : -1);
     } else {
-        conv_generic(a, stream);
+        conv_generic(a, cur_);
     }
 }
 
@@ -111,7 +120,7 @@ void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, 
     g.a = a; g.a_ld = lv.ld; g.b = b; g.b_ld = lv.ld; g.res = res; g.res_ld = lv.ld; g.y = y; g.y_ld = lv.ld;
     g.gamma = l.g; g.beta = l.b; g.C = l.C; g.pre_relu = pre_relu; g.post_gelu = post_gelu;
     g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
-    layer_norm(g, stream);
+    layer_norm(g, cur_);
 }
 
 // /root/reference/src/modules/DDSConv.cpp:84-111: x += gelu(LN2(conv1x1(gelu(LN1(dwconv(x))))))
@@ -320,7 +329,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     for (int u : M.up_rate) upS *= u;
     std::vector<size_t> stage_elems(M.n_up);
     size_t regA = 0, regB = 0;
-    { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)5 * M.ups[i].Cout * Ftot * S;
+    { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)(1 + 3 * M.n_resk) * M.ups[i].Cout * Ftot * S;
           if (i & 1) { if (stage_elems[i] > regB) regB = stage_elems[i]; } else { if (stage_elems[i] > regA) regA = stage_elems[i]; } } }
     const long Lsb = Ftot * upS + B;           // MB-iSTFT: frames + 1 per utterance
     const int sbC = M.conv_post.Cout;
@@ -396,31 +405,39 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         const Lvl l2 = lvF(S2, 0);
         const size_t ce = (size_t)up.Cout * l2.total;
         float* reg = (i & 1) ? bf.regB : bf.regA;
-        float *bup = reg, *t1 = reg + ce, *pa = reg + 2 * ce, *pb = reg + 3 * ce, *xs = reg + 4 * ce;
+        float* bup = reg;
         ConvOpt ou; ou.in_act = 1; ou.slope = 0.1f;
         conv(up, x, lx, bup, l2, ou);
-        for (int j = 0; j < M.n_resk; j++) {   // /root/reference/src/modules/ResBlock1.cpp:55-69
-            const DResBlock& rb = M.rb[(size_t)i * M.n_resk + j];
+        // The nResK ResBlock chains only meet in the final sum (Generator_hifigan.cpp:159-173): run them
+        // concurrently on separate HIP streams so that a batch-1 stage (a few hundred workgroups per
+        // conv) keeps all 256 CUs busy and one chain's tail overlaps another chain's head.
+        const int nk = M.n_resk;
+        const bool fork = nk > 1 && nk <= 8;
+        if (fork) (void)hipEventRecord(ev_fork_, stream);
+        const float* outs[8];
+        for (int j = 0; j < nk; j++) {   // /root/reference/src/modules/ResBlock1.cpp:55-69
+            const DResBlock& rb = M.rb[(size_t)i * nk + j];
+            float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce;
+            if (fork) { cur_ = aux_[j % kAux]; if (j < kAux) (void)hipStreamWaitEvent(cur_, ev_fork_, 0); }
             const float* cur = bup;
             const int nd = (int)rb.c1.size();
             for (int d = 0; d < nd; d++) {
                 ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
                 conv(rb.c1[d], cur, l2, t1, l2, o1);
-                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur;
-                if (d < nd - 1) {
-                    float* nxt = (cur == pa) ? pb : pa;
-                    o2.epi = EPI_RESADD;
-                    conv(rb.c2[d], t1, l2, nxt, l2, o2);
-                    cur = nxt;
-                } else {       // xs = (rb_0 + rb_1 + ...) / nResK  (Generator_hifigan.cpp:159-173)
-                    o2.epi = EPI_RESADD_ACC; o2.aux = xs; o2.epi_scale = (float)M.n_resk;
-                    o2.epi_flag = j == 0 ? (M.n_resk == 1 ? 2 : 0) : (j == M.n_resk - 1 ? 2 : 1);
-                    if (M.n_resk == 1) { fill_zero(xs, (long)ce, stream); }
-                    conv(rb.c2[d], t1, l2, nullptr, l2, o2);
-                }
+                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur; o2.epi = EPI_RESADD;
+                float* nxt = (cur == pa) ? pb : pa;
+                conv(rb.c2[d], t1, l2, nxt, l2, o2);
+                cur = nxt;
             }
+            outs[j] = cur;
         }
-        x = xs; S = S2; lx = l2;
+        if (fork) {
+            for (int j = 0; j < nk && j < kAux; j++) { (void)hipEventRecord(ev_join_[j], aux_[j]); (void)hipStreamWaitEvent(stream, ev_join_[j], 0); }
+            cur_ = stream;
+        }
+        // xs = ((rb_0 + rb_1) + ...) / nResK, written over the (now dead) upsampler output
+        sum_scale(bup, outs, nk, (long)ce, stream);
+        x = bup; S = S2; lx = l2;
     }
     in_mfma_region_ = false;
     mark(6);

@@ -78,6 +78,10 @@ private:
     Arena arenaT_, arenaF_;
     char* pinned_ = nullptr; size_t pinned_cap_ = 0;
     hipEvent_t ev_[8] = {};
+    static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently
+    hipStream_t aux_[kAux] = {};
+    hipEvent_t ev_fork_ = nullptr, ev_join_[kAux] = {};
+    hipStream_t cur_ = nullptr;               // stream the conv()/ln() helpers launch on
     bool have_events_ = false;
     int cur_stage_ = 0;
     double flops_[4] = {0, 0, 0, 0};

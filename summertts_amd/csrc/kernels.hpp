@@ -85,6 +85,8 @@ void add_inplace(float* y, long y_ld, const float* x, long x_ld, int C, long n, 
 void add_ubias(float* y, long ld, const float* u, int C, SegView seg, int B, int max_len, hipStream_t st);
 void gather_speaker(const float* emb_g, int spk_num, int gin, const int* sid, int B, float* g, hipStream_t st);
 void fill_zero(float* p, long n, hipStream_t st);
+// y = (((r0 + r1) + r2) + ...) / count  (ResBlock sum, /root/reference/src/models/Generator_hifigan.cpp:159-173)
+void sum_scale(float* y, const float* const* r, int count, long n, hipStream_t st);
 void flip_channels(float* x, long ld, int C, long n, float* tmp, hipStream_t st);
 
 // SDP spline step: (r0, r1) -> (spline^-1(r1 | h), r0) ; h = [29][ld]

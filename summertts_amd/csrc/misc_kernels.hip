@@ -190,6 +190,36 @@ void fill_zero(float* p, long n, hipStream_t st) {
     hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
 }
 
+struct SumPtrs { const float* r[8]; };
+__global__ void sum_scale_kernel(float* y, SumPtrs p, int count, float div, long n, int vec) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (vec && i + 3 < n) {
+        float4 a = *reinterpret_cast<const float4*>(p.r[0] + i);
+        for (int k = 1; k < count; k++) {
+            const float4 b = *reinterpret_cast<const float4*>(p.r[k] + i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        a.x = a.x / div; a.y = a.y / div; a.z = a.z / div; a.w = a.w / div;
+        *reinterpret_cast<float4*>(y + i) = a;
+    } else {
+        for (long j = i; j < n && j < i + 4; j++) {
+            float a = p.r[0][j];
+            for (int k = 1; k < count; k++) a += p.r[k][j];
+            y[j] = a / div;
+        }
+    }
+}
+void sum_scale(float* y, const float* const* r, int count, long n, hipStream_t st) {
+    if (n <= 0 || count <= 0 || count > 8) return;
+    SumPtrs p;
+    for (int k = 0; k < 8; k++) p.r[k] = r[k < count ? k : 0];
+    int vec = ((uintptr_t)y & 15) == 0;
+    for (int k = 0; k < count; k++) vec = vec && (((uintptr_t)r[k] & 15) == 0);
+    long thr = (n + 3) / 4;
+    hipLaunchKernelGGL(sum_scale_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, y, p, count, (float)count, n, vec);
+}
+
 // channel reversal (/root/reference/src/nn_op/nn_flip.cpp:3-15); only needed when n_flows is odd --
 // otherwise the flips are folded into the coupling weights at load time.
 __global__ void flip_copy_kernel(const float* x, long ld, int C, long n, float* tmp) {

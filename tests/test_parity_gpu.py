@@ -163,7 +163,7 @@ def test_full_size_properties(kind):
     slow = syn.infer_ids(ids128, 0, 1.5)
     assert (syn.durations(128) >= dur).all() and slow.size > a.size   # lengthScale only stretches
     # batch invariance at full size
-    ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate((40, 128, 77))]
+    ids = [sb.synthetic_ids(40, cfg.vocab, salt=1), ids128, sb.synthetic_ids(77, cfg.vocab, salt=2)]
     batch = syn.infer_batch(ids)
     assert_pcm_close(batch[1], a, "batched vs single (automatic kernel choice)")
     syn.set_conv_mode(6)            # pinned kernel variant: bit-exact batch invariance
