@@ -294,7 +294,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
 // ------------------------------------------------------------------------------------------------
 template <int MW, int NW>
 __global__ __launch_bounds__(MW * NW <= 1 ? 1024 : (MW * NW <= 2 ? 512 : 256)) void conv_mfma_splitk_kernel(ConvArgs a, int mtiles) {
-    constexpr int G = 4, D = 3, E = MW * NW * 16;
+    constexpr int G = 4, E = MW * NW * 16;
+    constexpr int D = MW * NW == 1 ? 6 : (MW * NW == 2 ? 4 : 3);   // register ring depth (groups in flight)
     extern __shared__ __attribute__((aligned(16))) float red[];   // [KS][E][64]
     const int KS = blockDim.x >> 6;
     const int b = blockIdx.z;

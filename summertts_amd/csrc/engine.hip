@@ -174,7 +174,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         offT[b] = (int)Ttot; lenT[b] = n[b]; Ttot += n[b]; if (n[b] > maxT) maxT = n[b];
     }
     if (Ttot > (1 << 24)) return fail(STS_EINVAL, "batch too large");
-    if ((size_t)(M.hidden / 2 + 8 + maxT) * 4 > 150 * 1024) return fail(STS_EINVAL, "utterance too long for the attention kernel");
+    if ((size_t)(M.hidden / 2 + 8 + 5 * (size_t)maxT) * 4 > 150 * 1024) return fail(STS_EINVAL, "utterance too long for the attention kernel");
     if (have_forced && (long)forced_dur.size() != Ttot) { have_forced = false; return fail(STS_EINVAL, "forced durations do not match the batch"); }
 
     const int H = M.hidden, C = M.inter;
@@ -275,13 +275,13 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         conv(M.sdp_pre, bt.x, lvT, bt.dh, lvT, op);
         dds(M.sdp_dds, bt.dh, bt.dt1, bt.dt2, lvT);
         conv(M.sdp_proj, bt.dh, lvT, bt.dc, lvT, ConvOpt());
-        fill_zero(bt.dr[0], Ttot, stream); fill_zero(bt.dr[1], Ttot, stream);
+        HIPCK(hipMemsetAsync(bt.dr[0], 0, (size_t)2 * ((Ttot * 4 + 255) / 256 * 256), stream));   // dr[0], dr[1] are adjacent
         float *r0 = bt.dr[0], *r1 = bt.dr[1], *n0 = bt.dr[2], *n1 = bt.dr[3];
         for (int i = M.sdp_flows - 1; i > 0; i--) {   // flow 0 is skipped; z == 0 because noise_scale == 0
             const DConvFlow& cf = M.cf[i];
             Lvl l1 = lvT;
-            conv(cf.pre, r0, l1, bt.dhh, lvT, ConvOpt());
-            add_inplace(bt.dhh, Ttot, bt.dc, Ttot, cf.filter, Ttot, stream);
+            ConvOpt oa; oa.epi = EPI_RESADD; oa.res = bt.dc;   // DDSConv(x + g): the "+ g" rides on the pre conv
+            conv(cf.pre, r0, l1, bt.dhh, lvT, oa);
             dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT);
             conv(cf.proj, bt.dhh, lvT, bt.dp29, lvT, ConvOpt());
             spline_step(bt.dp29, Ttot, sqrtf((float)cf.filter), r0, r1, n0, n1, Ttot, stream);

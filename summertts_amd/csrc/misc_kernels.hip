@@ -36,10 +36,12 @@ void embed(const int* ids, const float* emb, int vocab, int H, float scale, floa
 // LayerNorm over channels per time step (/root/reference/src/nn_op/nn_layer_norm.cpp:65-86):
 // var = sum(x^2)/C - mean^2, eps 1e-5 added in double.  Fused: input add, relu before, gelu after,
 // residual add after.
-// Workgroup = 32 time steps x 8 channel groups: loads coalesce along time (128-B rows), the channel
-// sum is split 8 ways and combined through LDS.
-__global__ __launch_bounds__(256) void layer_norm_kernel(LnArgs a) {
-    __shared__ float rs[8][33], rq[8][33];
+// Workgroup = 32 time steps x 32 channel groups (1024 threads): loads coalesce along time (128-B rows),
+// each thread touches only C/32 channels (6 at C = 192) so the kernel is ~2 memory round trips deep;
+// the channel sum is combined through LDS.
+constexpr int LN_G = 32;
+__global__ __launch_bounds__(1024) void layer_norm_kernel(LnArgs a) {
+    __shared__ float rs[LN_G][33], rq[LN_G][33];
     const int b = blockIdx.y;
     const int len = seg_len(a.seg, b);
     const int tx = threadIdx.x & 31, cy = threadIdx.x >> 5;
@@ -48,8 +50,8 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(LnArgs a) {
     const size_t p = (size_t)seg_start(a.seg, b) + (live ? pos : 0);
     float s = 0.f, sq = 0.f;
     if (live) {
-#pragma unroll 4
-        for (int c = cy; c < a.C; c += 8) {
+#pragma unroll 8
+        for (int c = cy; c < a.C; c += LN_G) {
             float v = a.a[(size_t)c * a.a_ld + p];
             if (a.b) v += a.b[(size_t)c * a.b_ld + p];
             if (a.pre_relu && v < 0.f) v = 0.f;
@@ -61,13 +63,13 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(LnArgs a) {
     if (!live) return;
     s = 0.f; sq = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { s += rs[k][tx]; sq += rq[k][tx]; }
+    for (int k = 0; k < LN_G; k++) { s += rs[k][tx]; sq += rq[k][tx]; }
     const float mean = s / (float)a.C;
     const float scale = (float)(1. / (float)a.C);
     const float var = sq * scale - mean * mean;
     const float den = (float)sqrt((double)var + 1e-05);
-#pragma unroll 4
-    for (int c = cy; c < a.C; c += 8) {
+#pragma unroll 8
+    for (int c = cy; c < a.C; c += LN_G) {
         float v = a.a[(size_t)c * a.a_ld + p];
         if (a.b) v += a.b[(size_t)c * a.b_ld + p];
         if (a.pre_relu && v < 0.f) v = 0.f;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(LnArgs a) {
 }
 void layer_norm(const LnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((a.max_len + 31) / 32, a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((a.max_len + 31) / 32, a.B), dim3(1024), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -87,6 +89,8 @@ void layer_norm(const LnArgs& a, hipStream_t st) {
 // /root/reference/src/modules/multi_head_attention.cpp:201-295 with the skew/pad/reshape of
 // :133-199 reduced to its banded meaning:  S[i][j] = (q_i/sqrt(kc)) . k_j + [|j-i|<=win] (q_i/sqrt(kc)) . relK[j-i+win]
 // P = exp(S)/sum exp(S) (nn_softmax.cpp:5-28: no max shift) ;  O_i = sum_j P_ij v_j + sum_{|j-i|<=win} P_ij relV[j-i+win].
+// Parallel layout: the 4 waves split the kc channels of the score dot product (partials in LDS), lanes run
+// over keys; the P.V product runs 4 channels per lane-pass so 4 loads are in flight per wave.
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.z, h = blockIdx.y, i = blockIdx.x;
@@ -94,50 +98,74 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     if (i >= T) return;
     const size_t base = (size_t)seg_start(a.seg, b);
     const int kc = a.kc, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* qs = sm;            // [kc]
-    float* red = sm + kc;      // [8]
-    float* P = sm + kc + 8;    // [T]
+    float* qs = sm;                 // [kc]
+    float* red = sm + kc;           // [8]
+    float* P = sm + kc + 8;         // [T]
+    float* part = P + T;            // [4][T] partial scores
     const float sq = sqrtf((float)kc);
     for (int c = tid; c < kc; c += 256) qs[c] = a.q[(size_t)(h * kc + c) * a.ld + base + i] / sq;
     __syncthreads();
-    float part = 0.f;
-    for (int j = tid; j < T; j += 256) {
-        float s = 0.f;
+    // wave w owns channels [c0, c1)
+    const int cw = (kc + 3) / 4, c0 = wave * cw, c1 = c0 + cw < kc ? c0 + cw : kc;
+    for (int j = lane; j < T; j += 64) {
         const float* kp = a.k + (size_t)(h * kc) * a.ld + base + j;
-        for (int c = 0; c < kc; c++) s += qs[c] * kp[(size_t)c * a.ld];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int c = c0;
+        for (; c + 3 < c1; c += 4) {
+            s0 += qs[c] * kp[(size_t)c * a.ld];
+            s1 += qs[c + 1] * kp[(size_t)(c + 1) * a.ld];
+            s2 += qs[c + 2] * kp[(size_t)(c + 2) * a.ld];
+            s3 += qs[c + 3] * kp[(size_t)(c + 3) * a.ld];
+        }
+        for (; c < c1; c++) s0 += qs[c] * kp[(size_t)c * a.ld];
+        float s = (s0 + s1) + (s2 + s3);
         const int r = j - i + a.win;
         if (a.win > 0 && r >= 0 && r < a.px) {
-            float s2 = 0.f;
-            for (int c = 0; c < kc; c++) s2 += qs[c] * a.relk[(size_t)c * a.px + r];
-            s += s2;
+            float s2r = 0.f;
+            for (int cc = c0; cc < c1; cc++) s2r += qs[cc] * a.relk[(size_t)cc * a.px + r];
+            s += s2r;
         }
-        const float e = expf(s);
-        P[j] = e;
-        part += e;
+        part[wave * T + j] = s;
     }
-    part = wave_sum(part);
-    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    float psum = 0.f;
+    for (int j = tid; j < T; j += 256) {
+        const float e = expf((part[j] + part[T + j]) + (part[2 * T + j] + part[3 * T + j]));
+        P[j] = e;
+        psum += e;
+    }
+    psum = wave_sum(psum);
+    if (lane == 0) red[wave] = psum;
     __syncthreads();
     const float sum = red[0] + red[1] + red[2] + red[3];
     for (int j = tid; j < T; j += 256) P[j] = P[j] / sum;
     __syncthreads();
-    for (int c = wave; c < kc; c += 4) {
-        const float* vp = a.v + (size_t)(h * kc + c) * a.ld + base;
-        float o = 0.f;
-        for (int j = lane; j < T; j += 64) o += P[j] * vp[j];
-        float o2 = 0.f;
-        if (a.win > 0 && lane < a.px) {
-            const int j = i + lane - a.win;
-            if (j >= 0 && j < T) o2 = P[j] * a.relv[(size_t)c * a.px + lane];
+    for (int cb = wave * 4; cb < kc; cb += 16) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f}, o2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = cb + u;
+            if (c < kc) {
+                const float* vp = a.v + (size_t)(h * kc + c) * a.ld + base;
+                for (int j = lane; j < T; j += 64) o[u] += P[j] * vp[j];
+                if (a.win > 0 && lane < a.px) {
+                    const int j = i + lane - a.win;
+                    if (j >= 0 && j < T) o2[u] = P[j] * a.relv[(size_t)c * a.px + lane];
+                }
+            }
         }
-        o = wave_sum(o);
-        o2 = wave_sum(o2);
-        if (lane == 0) a.o[(size_t)(h * kc + c) * a.ld + base + i] = o + o2;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float t = wave_sum(o[u]);
+            const float t2 = wave_sum(o2[u]);
+            const int c = cb + u;
+            if (lane == 0 && c < kc) a.o[(size_t)(h * kc + c) * a.ld + base + i] = t + t2;
+        }
     }
 }
 void attention(const AttnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
-    size_t lds = (size_t)(a.kc + 8 + a.max_len) * sizeof(float);
+    size_t lds = (size_t)(a.kc + 8 + 5 * (size_t)a.max_len) * sizeof(float);
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attention_kernel, dim3(a.max_len, a.nheads, a.B), dim3(256), lds, st, a);
