@@ -146,22 +146,31 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
     const int nsteps = nchunk * a.ntap;
 
     // A fragment of step s = chunk*ntap + tap : lane holds W[tap][chunk*CK + 2p + half][mbase + mw*32 + l31].
-    // Row tiles beyond Cout_pad read whatever follows in the (slack-padded) weight store: those
-    // accumulator rows are never stored, so the loop carries no per-lane predicate at all.
+    // A fragment through a raw buffer descriptor: one per-lane VGPR offset (row parity + column) for the
+    // whole kernel, the (tap, channel pair, row tile) part of the address rides in the scalar offset --
+    // no 64-bit vector address arithmetic per load.  Row tiles beyond Cout_pad fall outside the
+    // descriptor and read as 0.
+    const rsrc_t wrs = make_rsrc(w, (unsigned)((size_t)a.ntap * a.Cin_pad * a.Cout_pad * 4));
+    const unsigned a_voff = (unsigned)(((size_t)half * a.Cout_pad + mbase + l31) * 4);
     auto load_a = [&](int c, int j, float (&dst)[CK / 2][MW]) {
-        const float* wp = w + ((size_t)j * a.Cin_pad + (size_t)c * CK + half) * a.Cout_pad + mbase + l31;
+        const unsigned sbase = (unsigned)((((size_t)j * a.Cin_pad + (size_t)c * CK) * a.Cout_pad) * 4);
 #pragma unroll
         for (int p = 0; p < CK / 2; p++)
 #pragma unroll
-            for (int i = 0; i < MW; i++) dst[p][i] = wp[(size_t)(2 * p) * a.Cout_pad + i * 32];
+            for (int i = 0; i < MW; i++)
+                dst[p][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    wrs, (int)a_voff, (int)(sbase + (unsigned)(2 * p) * (unsigned)a.Cout_pad * 4u + (unsigned)i * 128u), 0));
     };
     // B fragment of tap j: the staged LDS rows read at the tap's column shift
-    auto load_b = [&](int j, float (&dst)[CK / 2][NW]) {
+    // the LDS tile is double-buffered (chunk c lives in buffer c & 1): the next chunk's tile is written
+    // while the current chunk's last MFMAs issue, and a single barrier per chunk publishes it
+    auto load_b = [&](int bufi, int j, float (&dst)[CK / 2][NW]) {
+        const float* sb = smem + bufi * (CK * ldsw);
         const int bcol0 = wn * NW * 32 + l31 + j * a.tap_step + a.tap_off - lo;
 #pragma unroll
         for (int p = 0; p < CK / 2; p++)
 #pragma unroll
-            for (int q = 0; q < NW; q++) dst[p][q] = smem[(2 * p + half) * ldsw + bcol0 + q * 32];
+            for (int q = 0; q < NW; q++) dst[p][q] = sb[(2 * p + half) * ldsw + bcol0 + q * 32];
     };
 
     // ---- input staging: every thread owns RI columns of the window for all CK rows of a chunk.
@@ -189,33 +198,32 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
             for (int i = 0; i < RI; i++) xr[r][i] = buf_load(rs, xoff[i]);   // raw: activation is applied at store time
         }
     };
-    auto stage_chunk = [&](int c) {
-        __syncthreads();   // previous chunk's readers are done with the LDS tile
+    auto store_tile = [&](int bufi) {      // registers (chunk loaded earlier) -> LDS buffer, fused input activation
+        float* sb = smem + bufi * (CK * ldsw);
 #pragma unroll
         for (int r = 0; r < CK; r++)
 #pragma unroll
             for (int i = 0; i < RI; i++) {
                 float v = xr[r][i];
-                if (a.in_act) v = v < 0.f ? v * a.in_slope : v;   // fused input leaky-relu / relu
-                smem[r * ldsw + tid + i * NTHR] = v;
+                if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
+                sb[r * ldsw + tid + i * NTHR] = v;
             }
-        __syncthreads();
-        if (c + 1 < nchunk) load_x(c + 1);
     };
 
     // ---- main loop over steps (chunk, tap), unrolled by two with ping-pong fragment buffers: while
-    // step s issues its MFMAs, the A fragment (global/L2) and the B fragment (LDS) of step s+1 are
-    // already in flight into the other buffer.  No register copies, no waits on the fresh loads.
+    // step s issues its MFMAs, the A fragment (L2) and the B fragment (LDS) of step s+1 are already in
+    // flight into the other buffer.  No register copies, no waits on the fresh loads.
     float fa0[CK / 2][MW], fa1[CK / 2][MW], fb0[CK / 2][NW], fb1[CK / 2][NW];
     int sc = 0, sj = 0;   // chunk / tap of the current step
     auto do_step = [&](float (&acur)[CK / 2][MW], float (&anxt)[CK / 2][MW], float (&bcur)[CK / 2][NW],
                        float (&bnxt)[CK / 2][NW], int s) {
-        if (sj == 0) { stage_chunk(sc); load_b(0, bcur); }
+        const bool last_tap = sj + 1 == a.ntap;
         int nj = sj + 1, nc = sc;
-        if (nj == a.ntap) { nj = 0; nc = sc + 1; }
+        if (last_tap) { nj = 0; nc = sc + 1; }
         if (s + 1 < nsteps) {
             load_a(nc, nj, anxt);
-            if (nj != 0) load_b(nj, bnxt);
+            if (!last_tap) load_b(sc & 1, nj, bnxt);
+            else store_tile(nc & 1);          // chunk nc's tile (in registers since the start of chunk sc)
         }
 #pragma unroll
         for (int p = 0; p < CK / 2; p++)
@@ -224,10 +232,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
 #pragma unroll
                 for (int q = 0; q < NW; q++)
                     acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p][i], bcur[p][q], acc[i][q], 0, 0, 0);
+        if (last_tap && s + 1 < nsteps) {
+            __syncthreads();                  // tile nc visible to all waves; everyone is done reading tile sc
+            load_b(nc & 1, 0, bnxt);
+            if (nc + 1 < nchunk) load_x(nc + 1);
+        }
         sj = nj; sc = nc;
     };
     load_x(0);
+    store_tile(0);
     load_a(0, 0, fa0);
+    __syncthreads();
+    load_b(0, 0, fb0);
+    if (nchunk > 1) load_x(1);
     for (int s = 0; s < nsteps; s += 2) {
         do_step(fa0, fa1, fb0, fb1, s);
         if (s + 1 < nsteps) do_step(fa1, fa0, fb1, fb0, s + 1);
@@ -454,25 +471,16 @@ bool conv_mfma_eligible(const ConvArgs& a) {
     return true;
 }
 
+// Tile choice, from tools/conv_bench.py on MI355X (profiles/r01_conv_microbench.log).  All candidates are
+// 128 columns wide (4 waves x 32 columns); a wave owns a 64-row strip (A fragment reused over two row
+// tiles) when the output rows fill it and the launch still yields >= 2 workgroups per CU, else a 32-row
+// strip; below one workgroup per CU the split-K kernel takes over (launch_splitk).  The gated WaveNet
+// conv needs the (tanh, sigmoid) row-tile pair in one wave: 64x128.
 static int pick_tile(const ConvArgs& a, int nphase) {
-    double best = -1;
-    int best_i = 4;
-    for (int i = 0; i < kNumTiles; i++) {
-        const TileCfg& t = kTiles[i];
-        if (a.epi == EPI_GATE && t.MW != 2) continue;
-        int MT = 32 * t.MW * t.WM, NT = 32 * t.NW * t.WN;
-        int mt = (a.Cout_pad + MT - 1) / MT;
-        double eff = (double)a.Cout_pad / (double)(mt * MT);
-        // expected blocks: sum over utterances is approximated with max_n * B (upper bound)
-        double ntl = (double)((a.max_n + NT - 1) / NT);
-        double blocks = ntl * mt * nphase * a.B;
-        double neff = (double)a.max_n / (ntl * NT);
-        double fill = blocks >= 512 ? 1.0 : blocks / 512.0;
-        double big = (MT * NT >= 16384) ? 1.0 : (MT * NT >= 8192 ? 0.93 : 0.85);
-        double score = eff * neff * fill * big;
-        if (score > best) { best = score; best_i = i; }
-    }
-    return best_i;
+    if (a.epi == EPI_GATE) return 3;
+    const long nt = (a.max_n + 127) / 128;
+    if (a.Cout_pad % 64 == 0 && nt * (a.Cout_pad / 64) * nphase * a.B >= 512) return 3;
+    return 4;
 }
 
 template <int MW, int NW, int WM, int WN>
@@ -483,7 +491,7 @@ static void launch_mfma(const ConvArgs& a, int nphase, hipStream_t st) {
     int halo = first < last ? last - first : first - last;
     dim3 grid((a.max_n + NT - 1) / NT, mt * nphase, a.B);
     constexpr int NTHR = WM * WN * 64;
-    size_t lds = (size_t)CK * (((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR) * sizeof(float);
+    size_t lds = (size_t)2 * CK * (((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR) * sizeof(float);   // double-buffered tile
     (void)halo;
     hipLaunchKernelGGL((conv_mfma_kernel<MW, NW, WM, WN>), grid, dim3(WM * WN * 64), lds, st, a, mt);
 }
