@@ -68,6 +68,8 @@ def main():
                          "the heavier reading) | mbb_fix | ms_fix | istft_fix | ms_hifigan_sdp")
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
     ap.add_argument("--phonemes", type=int, default=128)
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterance lengths ~ U{64..256} (seed 1234) instead of --phonemes each (BASELINE configs[2..4])")
     ap.add_argument("--cpu-sample-phonemes", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=0)
@@ -96,7 +98,11 @@ def main():
 
     # global batch = world * batch utterances, sharded by utterance (no data-path collective)
     gB = world * args.batch
-    all_ids = [sb.synthetic_ids(args.phonemes, cfg.vocab, salt=u) for u in range(gB)]
+    if args.ragged:
+        lens = np.random.default_rng(1234).integers(64, 257, size=gB).tolist()
+    else:
+        lens = [args.phonemes] * gB
+    all_ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=u) for u, t in enumerate(lens)]
     shards = sharding.shard_utterances([len(a) for a in all_ids], world)
     mine = shards[rank]
     max_utts = max(len(s_) for s_ in shards)
@@ -172,7 +178,8 @@ def main():
             "data": "synthetic (seeded random weights in the reference .bin grammar; ids[i]=(i*37+11) mod vocab)",
             "config": {
                 "workload": f"configs[1]: single_speaker_fast (synthetic '{args.workload}' blob, "
-                            f"{blob.size} floats), batch={args.batch}/GPU, {args.phonemes} phonemes/utterance",
+                            f"{blob.size} floats), batch={args.batch}/GPU, "
+                            + ("64..256 phonemes/utterance (ragged)" if args.ragged else f"{args.phonemes} phonemes/utterance"),
                 "global_batch": gB, "phonemes": args.phonemes, "frames_per_step_rank0": int(last["frames"]),
                 "samples_per_step_rank0": int(last["samples"]), "parallelism": f"utterance-sharded x{world}",
             },

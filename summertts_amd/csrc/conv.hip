@@ -587,8 +587,56 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a, int rows)
     else epi_scalar(a, row, opos, v);
 }
 
+// Cout == 1 convs over long sequences (HiFi-GAN conv_post: 32 channels x 7 taps -> 1 sample, fused
+// leaky-relu in, tanh + int16 out).  The generic kernel re-reads every input 7x from L2; here a workgroup
+// stages its [Cin][256 + halo] window in LDS once (coalesced rows) and the weights in LDS too.
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y;
+    const int in_len = seg_len(a.in_seg, b), out_len = seg_len(a.out_seg, b);
+    const int n0 = blockIdx.x * 256;
+    if (n0 >= out_len) return;
+    const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
+    const int halo = (a.ntap - 1) * a.tap_step;            // tap_step > 0 here
+    const int W = 256 + halo;
+    float* xs = sm;                                        // [Cin][W]
+    float* ws = sm + (size_t)a.Cin * W;                    // [ntap][Cin]
+    for (int i = threadIdx.x; i < a.ntap * a.Cin; i += 256) {
+        const int j = i / a.Cin, ci = i - j * a.Cin;
+        ws[i] = a.w[((size_t)j * a.Cin_pad + ci) * a.Cout_pad];
+    }
+    for (int ci = 0; ci < a.Cin; ci++) {
+        const float* xrow = a.x + (size_t)ci * a.x_ld + in_base;
+        for (int col = threadIdx.x; col < W; col += 256) {
+            const int pos = n0 + a.tap_off + col;
+            float v = (pos >= 0 && pos < in_len) ? xrow[pos] : 0.f;
+            if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
+            xs[(size_t)ci * W + col] = v;
+        }
+    }
+    __syncthreads();
+    const int n = n0 + threadIdx.x;
+    if (n >= out_len) return;
+    float v = 0.f;
+    for (int j = 0; j < a.ntap; j++) {                     // same (tap, channel) order as conv_generic
+        const float* xp = xs + threadIdx.x + j * a.tap_step;
+        const float* wp = ws + j * a.Cin;
+        for (int ci = 0; ci < a.Cin; ci++) v += wp[ci] * xp[(size_t)ci * W];
+    }
+    if (a.bias) v += a.bias[0];
+    if (a.ubias) v += a.ubias[b];
+    epi_scalar(a, 0, out_base + (size_t)n, v);
+}
+
 void conv_generic(const ConvArgs& a, hipStream_t st) {
     if (a.max_n <= 0 || a.B <= 0) return;
+    if (a.Cout == 1 && !a.depthwise && !a.transposed && !a.in_reflect && a.tap_step > 0 && a.max_n >= 4096 && a.epi != EPI_GATE) {
+        const size_t lds = ((size_t)a.Cin * (256 + (a.ntap - 1) * a.tap_step) + (size_t)a.ntap * a.Cin) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(conv_cout1_kernel, dim3((a.max_n + 255) / 256, a.B), dim3(256), lds, st, a);
+            return;
+        }
+    }
     int rows = a.epi == EPI_GATE ? a.H : a.Cout;
     int nphase = a.transposed ? a.out_stride : 1;
     dim3 grid((a.max_n + 255) / 256, rows * nphase, a.B);

@@ -44,7 +44,15 @@ int Engine::init(const float* blob, int64_t bytes, int dev) {
     for (auto& e : ev_) HIPCK(hipEventCreate(&e));
     HIPCK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     for (auto& e : ev_join_) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& a : aux_) HIPCK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    {   // the chain with the largest kernel size (most FLOPs) is the critical path of a decoder stage:
+        // give it the highest queue priority, the lightest chain the lowest
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority (numerically greatest)
+        for (int k = 0; k < kAux; k++) {
+            int pr = lo + (hi - lo) * k / (kAux > 1 ? kAux - 1 : 1);
+            HIPCK(hipStreamCreateWithPriority(&aux_[k], hipStreamNonBlocking, pr));
+        }
+    }
     cur_ = stream;
     have_events_ = true;
     if (!blob || bytes < 32) return fail(STS_EMODEL, "model blob too small");
@@ -413,12 +421,23 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         // conv) keeps all 256 CUs busy and one chain's tail overlaps another chain's head.
         const int nk = M.n_resk;
         const bool fork = nk > 1 && nk <= 8;
-        if (fork) (void)hipEventRecord(ev_fork_, stream);
+        if (fork) {
+            (void)hipEventRecord(ev_fork_, stream);
+            for (int k = 0; k < kAux; k++) (void)hipStreamWaitEvent(aux_[k], ev_fork_, 0);
+        }
         const float* outs[8];
+        int rank[8];                      // rank[j] = number of chains cheaper than chain j
+        for (int j = 0; j < nk && j < 8; j++) {
+            rank[j] = 0;
+            for (int q = 0; q < nk && q < 8; q++) {
+                const int kj = M.rb[(size_t)i * nk + j].c1[0].k, kq = M.rb[(size_t)i * nk + q].c1[0].k;
+                if (kq < kj || (kq == kj && q < j)) rank[j]++;
+            }
+        }
         for (int j = 0; j < nk; j++) {   // /root/reference/src/modules/ResBlock1.cpp:55-69
             const DResBlock& rb = M.rb[(size_t)i * nk + j];
             float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce;
-            if (fork) { cur_ = aux_[j % kAux]; if (j < kAux) (void)hipStreamWaitEvent(cur_, ev_fork_, 0); }
+            if (fork) cur_ = aux_[rank[j] % kAux];
             const float* cur = bup;
             const int nd = (int)rb.c1.size();
             for (int d = 0; d < nd; d++) {
