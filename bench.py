@@ -157,6 +157,16 @@ def main():
         elapsed = float(tmax[0].item())
         total_samples = int(tsum[1].item())
 
+    # HBM traffic of the dominant kernel family comes from a separate rocprofv3 --pmc pass (the guide's
+    # recipe: FETCH_SIZE and WRITE_SIZE in their own runs), summarised by tools/summarize_profile.py
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        if args.workload == "hifigan_sdp" and args.batch == 1 and args.phonemes == 128 and not args.ragged:
+            traffic = {"hbm_bytes_per_launch": pmc["hbm_bytes_per_launch_corrected"], "source": "profiles/latest_pmc.json (" + pmc["tag"] + ")",
+                       "correction": pmc["correction"]}
+    except Exception:
+        pass
     if rank == 0:
         value = total_samples / elapsed
         achieved_tf = (mfma_flops / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
@@ -191,7 +201,8 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": dec_bytes / max(1, launches),
                 "launches_per_step": launches / max(1, args.steps),
                 "avg_launch_us": 1e3 * mfma_ms / max(1, launches),
                 "algorithmic_gflop_per_step": mfma_flops / max(1, args.steps) / 1e9,

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from summertts_amd import engine as eng
 
-F = 668
+F = int(os.environ.get('CONV_BENCH_FRAMES', '668'))
 SHAPES = [  # name, Cin, Cout, k, dil, L, stride_t
     ("te_qkv", 192, 576, 1, 1, 128, 0), ("te_ffn1", 192, 768, 3, 1, 128, 0), ("te_ffn2", 768, 192, 3, 1, 128, 0),
     ("flow_gate_like", 192, 384, 5, 1, F, 0), ("flow_rs", 192, 384, 1, 1, F, 0),
