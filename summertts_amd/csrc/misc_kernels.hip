@@ -105,12 +105,23 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const float sq = sqrtf((float)kc);
     for (int c = tid; c < kc; c += 256) qs[c] = a.q[(size_t)(h * kc + c) * a.ld + base + i] / sq;
     __syncthreads();
+    // banded relative-key logits q . relK[r], r = 0..px-1: one 16-lane group per r, shuffle-reduced
+    float* qrel = part + 4 * T;      // [16]
+    if (a.win > 0 && tid < 16 * a.px && tid < 256) {
+        const int r = tid >> 4, l16 = tid & 15;
+        float s = 0.f;
+        for (int c = l16; c < kc; c += 16) s += qs[c] * a.relk[(size_t)c * a.px + r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (l16 == 0) qrel[r] = s;
+    }
     // wave w owns channels [c0, c1)
     const int cw = (kc + 3) / 4, c0 = wave * cw, c1 = c0 + cw < kc ? c0 + cw : kc;
     for (int j = lane; j < T; j += 64) {
         const float* kp = a.k + (size_t)(h * kc) * a.ld + base + j;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int c = c0;
+#pragma unroll 2
         for (; c + 3 < c1; c += 4) {
             s0 += qs[c] * kp[(size_t)c * a.ld];
             s1 += qs[c + 1] * kp[(size_t)(c + 1) * a.ld];
@@ -118,19 +129,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             s3 += qs[c + 3] * kp[(size_t)(c + 3) * a.ld];
         }
         for (; c < c1; c++) s0 += qs[c] * kp[(size_t)c * a.ld];
-        float s = (s0 + s1) + (s2 + s3);
-        const int r = j - i + a.win;
-        if (a.win > 0 && r >= 0 && r < a.px) {
-            float s2r = 0.f;
-            for (int cc = c0; cc < c1; cc++) s2r += qs[cc] * a.relk[(size_t)cc * a.px + r];
-            s += s2r;
-        }
-        part[wave * T + j] = s;
+        part[wave * T + j] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     float psum = 0.f;
     for (int j = tid; j < T; j += 256) {
-        const float e = expf((part[j] + part[T + j]) + (part[2 * T + j] + part[3 * T + j]));
+        float sc = (part[j] + part[T + j]) + (part[2 * T + j] + part[3 * T + j]);
+        const int r = j - i + a.win;
+        if (a.win > 0 && r >= 0 && r < a.px) sc += qrel[r];
+        const float e = expf(sc);
         P[j] = e;
         psum += e;
     }
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 }
 void attention(const AttnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
-    size_t lds = (size_t)(a.kc + 8 + 5 * (size_t)a.max_len) * sizeof(float);
+    size_t lds = (size_t)(a.kc + 8 + 16 + 5 * (size_t)a.max_len) * sizeof(float);
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attention_kernel, dim3(a.max_len, a.nheads, a.B), dim3(256), lds, st, a);
