@@ -340,46 +340,59 @@ __global__ __launch_bounds__(MW * NW <= 1 ? 1024 : (MW * NW <= 2 ? 512 : 256)) v
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][q][r] = 0.f;
 
+    // K is walked in groups of G = 4 channel pairs (8 input channels of one tap); wave w takes groups
+    // w, w + KS, ...  The (tap, channel) position of a wave's next group is tracked incrementally in
+    // SCALAR registers (no integer division, no 64-bit vector address arithmetic): both operands go
+    // through raw buffer descriptors with the uniform part of the address in the scalar offset.
     const int gpt = a.Cin_pad / (2 * G);   // groups per tap
     const int ngroups = a.ntap * gpt;
     float ra[D][G][MW], rb[D][G][NW];
-
-    // x through ONE raw buffer descriptor based at this utterance's first sample: the two half-waves read
-    // different channels, so the channel row is folded into the per-lane byte offset; padding positions
-    // and padded channels use an out-of-range offset and come back as 0 from the range check.
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const int sKS = __builtin_amdgcn_readfirstlane(KS);
+    // x: one descriptor based at this utterance's first sample, rows folded into the offset
     // (the launcher only picks this kernel while Cin_pad * x_ld * 4 fits the 32-bit offset)
     const rsrc_t xrs = make_rsrc(a.x + in_base, (unsigned)(((size_t)(a.Cin - 1) * a.x_ld + orig_len) * 4));   // < kOOB
-    auto load_group = [&](int g, float (&fa)[G][MW], float (&fb)[G][NW]) {
-        const int j = g / gpt, c0 = (g - j * gpt) * 2 * G;
-        const int shift = j * a.tap_step + a.tap_off;
+    const rsrc_t wrs = make_rsrc(w, (unsigned)((size_t)a.ntap * a.Cin_pad * a.Cout_pad * 4));
+    const unsigned ld4 = (unsigned)a.x_ld * 4u;
+    const unsigned x_lane = (unsigned)half * ld4;                                       // odd channel of a pair
+    const unsigned a_lane = (unsigned)(((size_t)half * a.Cout_pad + m0 + l31) * 4);
+    const int lanepos = n0 + l31;
+    int lj = swave / gpt, lc = (swave - lj * gpt) * 2 * G;     // (tap, first channel) of the next group to LOAD
+    const int jstep = sKS / gpt, cstep = (sKS - jstep * gpt) * 2 * G;
+
+    auto load_group = [&](float (&fa)[G][MW], float (&fb)[G][NW]) {
+        const int shift = lj * a.tap_step + a.tap_off;
         unsigned off[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
-            const int pos = n0 + q * 32 + l31 + shift;
+            int pos = lanepos + q * 32 + shift;
             bool v = pos >= 0 && pos < in_len;
-            int sidx = pos;
-            if (a.in_reflect) { sidx = pos - 1; if (sidx < 0) { sidx = 1; v = v && orig_len > 1; } }
-            off[q] = v ? (unsigned)sidx * 4u : kOOB;
+            if (a.in_reflect) { pos = pos - 1; if (pos < 0) { pos = 1; v = v && orig_len > 1; } }
+            off[q] = v ? (unsigned)pos * 4u + x_lane : kOOB;
         }
+        const unsigned xs0 = (unsigned)lc * ld4;                                          // scalar
+        const unsigned ws0 = (unsigned)((((size_t)lj * a.Cin_pad + lc) * a.Cout_pad) * 4);   // scalar
 #pragma unroll
         for (int i = 0; i < G; i++) {
-            const int ci = c0 + 2 * i + half;
-            const unsigned rowoff = ci < a.Cin ? (unsigned)ci * (unsigned)a.x_ld * 4u : kOOB;
+            // channels lc + 2i (+ half).  The scalar offset is NOT part of the hardware range check, so padded
+            // channels (>= Cin) are masked through the vector offset explicitly.
+            const bool cv = lc + 2 * i + half < a.Cin;
 #pragma unroll
-            for (int q = 0; q < NW; q++) {
-                const unsigned o = (rowoff == kOOB || off[q] == kOOB) ? kOOB : rowoff + off[q];
-                fb[i][q] = buf_load(xrs, o);   // raw: activation applied when the group is consumed
-            }
-            const float* wp = w + ((size_t)j * a.Cin_pad + ci) * a.Cout_pad + m0 + l31;
+            for (int q = 0; q < NW; q++)
+                fb[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(cv ? off[q] : kOOB), (int)(xs0 + (unsigned)(2 * i) * ld4), 0));
 #pragma unroll
-            for (int k = 0; k < MW; k++) fa[i][k] = wp[k * 32];
+            for (int k = 0; k < MW; k++)
+                fa[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    wrs, (int)a_lane, (int)(ws0 + (unsigned)(2 * i) * (unsigned)a.Cout_pad * 4u + (unsigned)k * 128u), 0));
         }
+        lj += jstep; lc += cstep;
+        if (lc >= a.Cin_pad) { lc -= a.Cin_pad; lj++; }
     };
 
-    int gnext = wave;
+    int gnext = swave;
 #pragma unroll
-    for (int d = 0; d < D; d++) { if (gnext < ngroups) load_group(gnext, ra[d], rb[d]); gnext += KS; }
-    int gcur = wave;
+    for (int d = 0; d < D; d++) { if (gnext < ngroups) load_group(ra[d], rb[d]); gnext += sKS; }
+    int gcur = swave;
     while (gcur < ngroups) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -399,9 +412,9 @@ __global__ __launch_bounds__(MW * NW <= 1 ? 1024 : (MW * NW <= 2 ? 512 : 256)) v
                         for (int q = 0; q < NW; q++)
                             acc[k][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][i][k], bq[q], acc[k][q], 0, 0, 0);
                 }
-                if (gnext < ngroups) load_group(gnext, ra[d], rb[d]);
+                if (gnext < ngroups) load_group(ra[d], rb[d]);
             }
-            gnext += KS; gcur += KS;
+            gnext += sKS; gcur += sKS;
         }
     }
 
