@@ -134,8 +134,17 @@ void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, 
 // /root/reference/src/modules/DDSConv.cpp:84-111: x += gelu(LN2(conv1x1(gelu(LN1(dwconv(x))))))
 void Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv) {
     for (int i = 0; i < d.n; i++) {
-        conv(d.sep[i], h, lv, t1, lv, ConvOpt());
-        ln(d.n1[i], t1, nullptr, nullptr, t1, lv, 0, 1);
+        {   // depthwise conv fused into the LayerNorm that consumes it (one launch instead of two)
+            const DConv& c = d.sep[i];
+            LnArgs g;
+            memset(&g, 0, sizeof(g));
+            g.a = h; g.a_ld = lv.ld; g.y = t1; g.y_ld = lv.ld;
+            g.gamma = d.n1[i].g; g.beta = d.n1[i].b; g.C = d.n1[i].C; g.post_gelu = 1;
+            g.dw_w = c.w; g.dw_b = c.bias; g.dw_k = c.k; g.dw_dil = c.dil; g.dw_pad = c.pad; g.dw_ld = c.Cout_pad;
+            g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
+            flops_[cur_stage_] += 2.0 * c.macs_per_out * (double)lv.total;
+            layer_norm(g, cur_);
+        }
         conv(d.pw[i], t1, lv, t2, lv, ConvOpt());
         ln(d.n2[i], t2, nullptr, h, h, lv, 0, 1);
     }

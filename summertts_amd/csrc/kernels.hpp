@@ -60,6 +60,9 @@ struct LnArgs {
     const float* gamma; const float* beta;
     int C;
     int pre_relu, post_gelu;
+    // optional fused depthwise conv on the input: v = dw_b[c] + sum_j dw_w[j*dw_ld + c] * a[c][pos + j*dw_dil - dw_pad]
+    // (DDSConv's separable conv feeds straight into its LayerNorm, /root/reference/src/modules/DDSConv.cpp:97-100)
+    const float* dw_w; const float* dw_b; int dw_k, dw_dil, dw_pad, dw_ld;
     SegView seg; int B, max_len;
 };
 

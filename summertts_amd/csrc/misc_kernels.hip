@@ -40,6 +40,31 @@ void embed(const int* ids, const float* emb, int vocab, int H, float scale, floa
 // each thread touches only C/32 channels (6 at C = 192) so the kernel is ~2 memory round trips deep;
 // the channel sum is combined through LDS.
 constexpr int LN_G = 32;
+__device__ __forceinline__ float ln_input(const LnArgs& a, int c, size_t p, int pos, int len) {
+    float v;
+    if (a.dw_w) {       // fused depthwise conv (zero padding inside the utterance)
+        v = a.dw_b ? a.dw_b[c] : 0.f;
+        const float* row = a.a + (size_t)c * a.a_ld + (p - pos);
+        int j = 0;
+        for (; j + 2 < a.dw_k; j += 3) {        // 3 taps per pass: independent loads (k = 3 in every known model)
+            const int q0 = pos + j * a.dw_dil - a.dw_pad, q1 = q0 + a.dw_dil, q2 = q1 + a.dw_dil;
+            const float w0 = a.dw_w[(size_t)j * a.dw_ld + c], w1 = a.dw_w[(size_t)(j + 1) * a.dw_ld + c], w2 = a.dw_w[(size_t)(j + 2) * a.dw_ld + c];
+            const float x0 = row[q0 >= 0 && q0 < len ? q0 : pos], x1 = row[q1 >= 0 && q1 < len ? q1 : pos], x2 = row[q2 >= 0 && q2 < len ? q2 : pos];
+            v += w0 * ((q0 >= 0 && q0 < len) ? x0 : 0.f);
+            v += w1 * ((q1 >= 0 && q1 < len) ? x1 : 0.f);
+            v += w2 * ((q2 >= 0 && q2 < len) ? x2 : 0.f);
+        }
+        for (; j < a.dw_k; j++) {
+            const int q = pos + j * a.dw_dil - a.dw_pad;
+            if (q >= 0 && q < len) v += a.dw_w[(size_t)j * a.dw_ld + c] * row[q];
+        }
+    } else {
+        v = a.a[(size_t)c * a.a_ld + p];
+    }
+    if (a.b) v += a.b[(size_t)c * a.b_ld + p];
+    if (a.pre_relu && v < 0.f) v = 0.f;
+    return v;
+}
 __global__ __launch_bounds__(1024) void layer_norm_kernel(LnArgs a) {
     __shared__ float rs[LN_G][33], rq[LN_G][33];
     const int b = blockIdx.y;
@@ -48,15 +73,16 @@ __global__ __launch_bounds__(1024) void layer_norm_kernel(LnArgs a) {
     const int pos = blockIdx.x * 32 + tx;
     const bool live = pos < len;
     const size_t p = (size_t)seg_start(a.seg, b) + (live ? pos : 0);
+    constexpr int MAXV = 8;                 // values kept in registers between the two passes (C <= 256)
+    float vals[MAXV];
     float s = 0.f, sq = 0.f;
     if (live) {
-#pragma unroll 8
-        for (int c = cy; c < a.C; c += LN_G) {
-            float v = a.a[(size_t)c * a.a_ld + p];
-            if (a.b) v += a.b[(size_t)c * a.b_ld + p];
-            if (a.pre_relu && v < 0.f) v = 0.f;
-            s += v; sq += v * v;
+#pragma unroll
+        for (int u = 0; u < MAXV; u++) {
+            const int c = cy + u * LN_G;
+            if (c < a.C) { const float v = ln_input(a, c, p, pos, len); vals[u] = v; s += v; sq += v * v; }
         }
+        for (int c = cy + MAXV * LN_G; c < a.C; c += LN_G) { const float v = ln_input(a, c, p, pos, len); s += v; sq += v * v; }
     }
     rs[cy][tx] = s; rq[cy][tx] = sq;
     __syncthreads();
@@ -68,16 +94,18 @@ __global__ __launch_bounds__(1024) void layer_norm_kernel(LnArgs a) {
     const float scale = (float)(1. / (float)a.C);
     const float var = sq * scale - mean * mean;
     const float den = (float)sqrt((double)var + 1e-05);
-#pragma unroll 8
-    for (int c = cy; c < a.C; c += LN_G) {
-        float v = a.a[(size_t)c * a.a_ld + p];
-        if (a.b) v += a.b[(size_t)c * a.b_ld + p];
-        if (a.pre_relu && v < 0.f) v = 0.f;
+    auto finish = [&](int c, float v) {
         float o = ((v - mean) / den) * a.gamma[c] + a.beta[c];
         if (a.post_gelu) o = gelu_ref(o);
         if (a.res) o = a.res[(size_t)c * a.res_ld + p] + o;
         a.y[(size_t)c * a.y_ld + p] = o;
+    };
+#pragma unroll
+    for (int u = 0; u < MAXV; u++) {
+        const int c = cy + u * LN_G;
+        if (c < a.C) finish(c, vals[u]);
     }
+    for (int c = cy + MAXV * LN_G; c < a.C; c += LN_G) finish(c, ln_input(a, c, p, pos, len));
 }
 void layer_norm(const LnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
