@@ -175,26 +175,29 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const float sum = red[0] + red[1] + red[2] + red[3];
     for (int j = tid; j < T; j += 256) P[j] = P[j] / sum;
     __syncthreads();
-    for (int cb = wave * 4; cb < kc; cb += 16) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f}, o2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int c = cb + u;
-            if (c < kc) {
-                const float* vp = a.v + (size_t)(h * kc + c) * a.ld + base;
-                for (int j = lane; j < T; j += 64) o[u] += P[j] * vp[j];
-                if (a.win > 0 && lane < a.px) {
-                    const int j = i + lane - a.win;
-                    if (j >= 0 && j < T) o2[u] = P[j] * a.relv[(size_t)c * a.px + lane];
+    // P.V: one thread per (channel, half of the keys): every load is independent (deep pipelining, no
+    // cross-lane reduction per channel); the two halves meet through one shuffle.
+    for (int cc = tid >> 1; cc < kc; cc += 128) {
+        const int jh = tid & 1;
+        const int j0 = jh ? (T + 1) / 2 : 0, j1 = jh ? T : (T + 1) / 2;
+        const float* vp = a.v + (size_t)(h * kc + cc) * a.ld + base;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        int j = j0;
+        for (; j + 3 < j1; j += 4) {
+            o0 += P[j] * vp[j]; o1 += P[j + 1] * vp[j + 1]; o2 += P[j + 2] * vp[j + 2]; o3 += P[j + 3] * vp[j + 3];
+        }
+        for (; j < j1; j++) o0 += P[j] * vp[j];
+        float o = (o0 + o1) + (o2 + o3);
+        o += __shfl_xor(o, 1, 64);
+        if (jh == 0) {
+            float orel = 0.f;
+            if (a.win > 0) {
+                for (int r = 0; r < a.px; r++) {
+                    const int jj = i + r - a.win;
+                    if (jj >= 0 && jj < T) orel += P[jj] * a.relv[(size_t)cc * a.px + r];
                 }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const float t = wave_sum(o[u]);
-            const float t2 = wave_sum(o2[u]);
-            const int c = cb + u;
-            if (lane == 0 && c < kc) a.o[(size_t)(h * kc + c) * a.ld + base + i] = t + t2;
+            a.o[(size_t)(h * kc + cc) * a.ld + base + i] = o + orel;
         }
     }
 }
