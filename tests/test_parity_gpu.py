@@ -186,3 +186,41 @@ def test_full_size_properties(kind):
     assert_wave_close(syn.tap("wave")[0], o["wave"], "full-size vs oracle")
     assert_pcm_close(syn.pcm_host(), o["pcm"], "full-size vs oracle")
     syn.close()
+
+
+def test_long_utterance_and_big_ragged_batch():
+    """test/main.cpp joins a whole file into ONE utterance: T in the thousands must work (attention keeps a
+    T-long probability row in LDS), and so must a large ragged batch in one call."""
+    cfg = sb.tiny_cfg("hifigan_fix")
+    blob = sb.make_blob(cfg, 5)
+    syn = engine.Synthesizer(blob)
+    port = pyref.PortModel(blob)
+    ids = sb.synthetic_ids(1500, cfg.vocab, salt=2)
+    o = port.infer_ids(ids, 0, 1.0)
+    pcm = syn.infer_ids(ids, 0, 1.0)
+    assert (syn.durations(len(ids)) == o["durations"]).all()
+    assert_pcm_close(pcm, o["pcm"], "T=1500")
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 60, size=200)
+    batch_ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=i) for i, t in enumerate(lens)]
+    out = syn.infer_batch(batch_ids)
+    assert len(out) == 200
+    for i in (0, 57, 199):
+        assert_pcm_close(out[i], port.infer_ids(batch_ids[i], 0, 1.0)["pcm"], f"utt {i} of 200")
+    with pytest.raises(engine.StsError):
+        syn.infer_ids(sb.synthetic_ids(60000, cfg.vocab), 0, 1.0)   # beyond the attention kernel's LDS row
+    syn.close()
+
+
+def test_malformed_blobs_are_rejected():
+    cfg = sb.tiny_cfg("mbb_fix")
+    blob = sb.make_blob(cfg, 5)
+    for bad in (blob[: blob.size // 2], blob[:10], np.concatenate([[0, 0, 0, 9], blob[4:]]).astype(np.float32),
+                np.concatenate([[0, 0, 7, 0], blob[4:]]).astype(np.float32)):
+        with pytest.raises(engine.StsError) as ei:
+            engine.Synthesizer(np.ascontiguousarray(bad, np.float32))
+        assert "sts error -2" in str(ei.value)
+    # trailing bytes after the acoustic sections (the frontend sections of a real blob) are fine
+    syn = engine.Synthesizer(np.concatenate([blob, np.zeros(1000, np.float32)]))
+    assert syn.info.blob_floats_consumed == blob.size
+    syn.close()

@@ -19,8 +19,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(pattern):
+    files = glob.glob(pattern)
+    return max(files, key=os.path.getmtime)
+
+
 def counter_sum(d, family):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(d, "*", "*counter_collection.csv"))
     n, tot = 0, 0.0
     for r in csv.DictReader(open(f)):
         if family in r["Kernel_Name"]:
@@ -33,7 +38,7 @@ def main():
     tag, kt = sys.argv[1], sys.argv[2]
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    st = glob.glob(os.path.join(kt, "*", "*kernel_stats.csv"))[0]
+    st = newest(os.path.join(kt, "*", "*kernel_stats.csv"))
     shutil.copy(st, os.path.join(out, f"{tag}_kernel_stats.csv"))
     fam = "conv_mfma_kernel"
     rows = [r for r in csv.DictReader(open(st)) if fam in r["Name"]]
