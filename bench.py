@@ -80,10 +80,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("STS_BENCH_FORCE_DIST") == "1"   # exercise the RCCL gather path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -112,7 +114,7 @@ def main():
 
     def step():
         n_out = syn.run_batch(ids, sid, ls)
-        if world == 1:
+        if dist is None:
             pcm = syn.pcm_host()
             return int(n_out.sum()), pcm
         pcm, counts = sharding.gather_pcm(syn, n_out, dist, torch, rank, world, max_utts)
@@ -214,9 +216,19 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(blob, cfg, cfg.vocab, args.cpu_sample_phonemes)
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": str(e)}
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if dist is not None:
         dist.destroy_process_group()
+    if result_line is not None:      # the JSON line is the LAST thing on stdout (RCCL may print banners earlier)
+        sys.stdout.flush()
+        print(result_line, flush=True)
+    if dist is not None:
+        # RCCL prints a banner from an exit handler; leave without running it so that the JSON stays last
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
