@@ -476,7 +476,8 @@ bool conv_mfma_eligible(const ConvArgs& a) {
     if (a.depthwise) return false;
     // narrow outputs (e.g. the 29-row spline-parameter projection) still go to the matrix cores: the
     // weights are zero-padded to a 32-row tile and rows >= Cout are dropped in the epilogue
-    if (a.Cin < 32 || a.Cout < 8) return false;
+    if (a.Cin < 32) return false;
+    if (a.Cout < 8 && a.max_n >= 4096) return false;   // long single-channel FIRs: conv_cout1_kernel is the better fit
     if (a.Cin_pad % CK != 0 || a.Cout_pad % 32 != 0) return false;
     int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
     int halo = first < last ? last - first : first - last;

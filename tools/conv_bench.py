@@ -16,6 +16,8 @@ SHAPES = [  # name, Cin, Cout, k, dil, L, stride_t
     ("up3", 128, 64, 4, 1, 64 * F, 2),
     ("s3_k3", 64, 64, 3, 1, 128 * F, 0), ("s3_k11d5", 64, 64, 11, 5, 128 * F, 0),
     ("up4", 64, 32, 4, 1, 128 * F, 2),
+    ("mbb_s1_k3", 256, 256, 3, 1, 4 * F, 0), ("mbb_s1_k11d5", 256, 256, 11, 5, 4 * F, 0),
+    ("mbb_s2_k3", 128, 128, 3, 1, 16 * F, 0), ("mbb_s2_k11d5", 128, 128, 11, 5, 16 * F, 0),
     ("s4_k3", 32, 32, 3, 1, 256 * F, 0), ("s4_k7d3", 32, 32, 7, 3, 256 * F, 0), ("s4_k11d5", 32, 32, 11, 5, 256 * F, 0),
 ]
 MODES = {0: "auto", 2: "128x128", 3: "64x256", 4: "32x512", 5: "64x128", 6: "32x128", 7: "32x256", 8: "splitk32", 9: "splitk64"}
