@@ -69,14 +69,6 @@ __device__ __forceinline__ void epi_scalar(const ConvArgs& a, int row, size_t op
     switch (a.epi) {
         case EPI_STORE: a.y[(size_t)row * a.y_ld + opos] = v; break;
         case EPI_RESADD: a.y[(size_t)row * a.y_ld + opos] = v + a.res[(size_t)row * a.res_ld + opos]; break;
-        case EPI_RESADD_ACC: {
-            float t = v + a.res[(size_t)row * a.res_ld + opos];
-            float* p = a.aux + (size_t)row * a.aux_ld + opos;
-            if (a.epi_flag == 0) *p = t;
-            else if (a.epi_flag == 1) *p = *p + t;
-            else *p = (*p + t) / a.epi_scale;
-            break;
-        }
         case EPI_SUB: { float* p = a.y + (size_t)row * a.y_ld + opos; *p = *p - v; break; }
         case EPI_RESSKIP: {
             if (a.Cout != a.H && row < a.H) {

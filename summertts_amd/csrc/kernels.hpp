@@ -23,7 +23,6 @@ struct SegView {
 enum Epilogue : int {
     EPI_STORE = 0,       // y = v
     EPI_RESADD = 1,      // y = v + res
-    EPI_RESADD_ACC = 2,  // t = v + res ; aux = (flag==0 ? t : flag==1 ? aux + t : (aux + t) / scale)   (ResBlock sum)
     EPI_SUB = 3,         // y = y - v                                       (coupling: x1 -= m)
     EPI_GATE = 4,        // y = tanh(v_t) * sigmoid(v_s)                     (WN gated unit)
     EPI_RESSKIP = 5,     // rows <  H: y[row] += v ; rows >= H: aux[row-H] (+)= v   (WN res/skip)
@@ -36,8 +35,8 @@ struct ConvArgs {
     const float* w;                 // packed weights [ntap][Cin_pad][Cout_pad] (co contiguous); depthwise: [ntap][Cout_pad]
     const float* bias;              // [Cout_pad] (packed row order) or null
     const float* ubias; int ubias_ld;  // per-utterance bias [Cout][ubias_ld = B] or null
-    const float* res; long res_ld;  // residual input (EPI_RESADD*)
-    float* aux; long aux_ld;        // accumulator (EPI_RESADD_ACC) / skip output (EPI_RESSKIP) / float wave (EPI_TANH_PCM)
+    const float* res; long res_ld;  // residual input (EPI_RESADD)
+    float* aux; long aux_ld;        // skip output (EPI_RESSKIP) / float wave (EPI_TANH_PCM)
     int16_t* pcm;                   // EPI_TANH_PCM
     int Cin, Cout, Cin_pad, Cout_pad, ntap;
     int tap_step, tap_off;          // input position of output n, tap j: n + j*tap_step + tap_off
@@ -83,11 +82,9 @@ void conv_generic(const ConvArgs& a, hipStream_t st);
 void embed(const int* ids, const float* emb, int vocab, int H, float scale, float* x, long ld, int total, hipStream_t st);
 void layer_norm(const LnArgs& a, hipStream_t st);
 void attention(const AttnArgs& a, hipStream_t st);
-void add_inplace(float* y, long y_ld, const float* x, long x_ld, int C, long n, hipStream_t st);
 // y[c][seg b] += u[c*B + b]
 void add_ubias(float* y, long ld, const float* u, int C, SegView seg, int B, int max_len, hipStream_t st);
 void gather_speaker(const float* emb_g, int spk_num, int gin, const int* sid, int B, float* g, hipStream_t st);
-void fill_zero(float* p, long n, hipStream_t st);
 // y = (((r0 + r1) + r2) + ...) / count  (ResBlock sum, /root/reference/src/models/Generator_hifigan.cpp:159-173)
 void sum_scale(float* y, const float* const* r, int count, long n, hipStream_t st);
 void flip_channels(float* x, long ld, int C, long n, float* tmp, hipStream_t st);

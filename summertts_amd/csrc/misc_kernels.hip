@@ -210,17 +210,6 @@ void attention(const AttnArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void add_inplace_kernel(float* y, long y_ld, const float* x, long x_ld, int C, long n) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = blockIdx.y;
-    y[(size_t)c * y_ld + i] += x[(size_t)c * x_ld + i];
-}
-void add_inplace(float* y, long y_ld, const float* x, long x_ld, int C, long n, hipStream_t st) {
-    if (n <= 0 || C <= 0) return;
-    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256), C), dim3(256), 0, st, y, y_ld, x, x_ld, C, n);
-}
-
 __global__ void add_ubias_kernel(float* y, long ld, const float* u, SegView seg, int B) {
     const int b = blockIdx.z, c = blockIdx.y;
     const int pos = blockIdx.x * 256 + threadIdx.x;
@@ -245,15 +234,6 @@ void gather_speaker(const float* emb_g, int spk_num, int gin, const int* sid, in
     int n = gin * B;
     if (n <= 0) return;
     hipLaunchKernelGGL(gather_speaker_kernel, dim3((n + 255) / 256), dim3(256), 0, st, emb_g, spk_num, gin, sid, B, g);
-}
-
-__global__ void fill_zero_kernel(float* p, long n) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0.f;
-}
-void fill_zero(float* p, long n, hipStream_t st) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
 }
 
 struct SumPtrs { const float* r[8]; };
