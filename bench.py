@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--cpu-sample-phonemes", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=0)
+    ap.add_argument("--pipeline-engines", type=int, default=2,
+                    help="extra (not the headline): throughput with this many engines fed by concurrent host threads, "
+                         "so one utterance's latency-bound text side overlaps another's decoder; 0 disables")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +152,34 @@ def main():
     elapsed = time.perf_counter() - t0
     last = syn.profile()
 
+    # ---- extra figure: N engines on one GPU, one host thread each (serving-style pipelining of requests)
+    pipelined = None
+    if dist is None and args.pipeline_engines >= 2:
+        import threading
+        engines = [syn] + [eng.Synthesizer(blob, device=0) for _ in range(args.pipeline_engines - 1)]
+        for e_ in engines:
+            e_.set_conv_mode(args.conv_mode)
+            e_.set_profiling(False)
+            e_.run_batch(ids, sid, ls)
+        per_thread = max(4, args.steps // 2)
+        done = [0] * len(engines)
+
+        def worker(k):
+            for _ in range(per_thread):
+                n_out = engines[k].run_batch(ids, sid, ls)
+                engines[k].pcm_host()
+                done[k] += int(n_out.sum())
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(engines))]
+        tp0 = time.perf_counter()
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        tp = time.perf_counter() - tp0
+        pipelined = {"engines": len(engines), "value": sum(done) / tp, "unit": "samples/s", "x_realtime_16khz": sum(done) / tp / 16000.0,
+                     "ms_per_utterance": 1e3 * tp / (per_thread * len(engines) * max(1, len(ids)))}
+        syn.set_profiling(True)
+
     total_samples = samples
     if dist is not None:
         t = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device="cuda")
@@ -211,6 +242,8 @@ def main():
                 "decoder_min_hbm_gb_per_step": dec_bytes / max(1, args.steps) / 1e9,
             },
         }
+        if pipelined is not None:
+            out["pipelined_engines"] = pipelined
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(blob, cfg, cfg.vocab, args.cpu_sample_phonemes)

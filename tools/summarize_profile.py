@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 output under gpurun_out/ into the committed summaries under profiles/.
 
-  python tools/summarize_profile.py <round-tag> <kernel-trace-dir> [<pmc-fetch-dir> <pmc-write-dir> <steps-in-pmc-run>]
+  python tools/summarize_profile.py <round-tag> <kernel-trace-dir> [<pmc-fetch-dir> <pmc-write-dir> <steps-in-pmc-run> [<pmc-sq-dir>]]
 
 Writes profiles/<tag>_kernel_stats.csv (the --stats table), and, when PMC passes are given,
 profiles/<tag>_pmc.json + profiles/latest_pmc.json with the per-launch HBM traffic of the dominant
@@ -54,6 +54,25 @@ def main():
             "hbm_bytes_per_launch_corrected": (2.0 * fetch_kb / max(1, nf) + write_kb / max(1, nw)) * 1024.0,
             "correction": "read side x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B); WRITE_SIZE as reported",
             "launches_in_pmc_run": nf,
+        })
+        json.dump(summary, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)
+    if len(sys.argv) >= 7:      # SQ pass: MFMA-busy of the family (kernels are serialised under --pmc)
+        f = newest(os.path.join(sys.argv[6], "*", "*counter_collection.csv"))
+        disp = {}
+        for r in csv.DictReader(open(f)):
+            if fam not in r["Kernel_Name"]:
+                continue
+            d = disp.setdefault(r["Dispatch_Id"], {"t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+            d[r["Counter_Name"]] = float(r["Counter_Value"])
+        busy = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for d in disp.values())
+        gui = sum(d.get("GRBM_GUI_ACTIVE", 0.0) for d in disp.values()) / 8.0     # one copy per XCD
+        tns = sum(d["t"] for d in disp.values())
+        summary.update({
+            "mfma_busy_pct_serialised": 100.0 * busy / (1024.0 * gui) if gui else None,   # 256 CUs x 4 SIMDs
+            "shader_clock_ghz": gui / tns if tns else None,
+            "avg_launch_us_serialised": tns / max(1, len(disp)) / 1e3,
+            "hbm_gbps_serialised": summary.get("hbm_bytes_per_launch_corrected", 0.0) / (tns / max(1, len(disp))) if tns else None,
+            "note_serialised": "rocprofv3 --pmc serialises dispatches: the three concurrent ResBlock chains run one after another here",
         })
         json.dump(summary, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)
     json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
