@@ -6,19 +6,24 @@
 //   * implicit GEMM on the matrix cores with the exact-fp32 instruction v_mfma_f32_32x32x2_f32:
 //     M = output channels, N = time, K = (tap, input channel).  Only the TRUE taps are iterated
 //     (the reference multiplies by the zero-stuffed dilated kernel).
-//   * the input tile plus its dilated halo is staged ONCE per 16-channel chunk in LDS with the
-//     input activation (leaky-relu) fused into the staging; the B operand of every tap is the same
-//     LDS rows read at a shifted column (bank-conflict free: 32 consecutive floats per half-wave).
-//   * weights are repacked at load time to [tap][cin][cout] so the A operand is a coalesced
-//     128-B row read straight from L2 (each lane needs exactly one float per MFMA); the next tap's
-//     A fragment is prefetched into registers while the current tap's MFMAs issue.
-//   * bias, per-utterance conditioning, residual add, ResBlock accumulation, the WaveNet gate
-//     tanh*sigmoid, res/skip split and the flow's "x1 -= m" are epilogues on the accumulator
-//     registers -- no elementwise kernels, no extra HBM round trips.
+//   * the input tile plus its dilated halo is staged ONCE per 16-channel chunk in a double-buffered LDS
+//     tile (raw-buffer loads: the hardware range check is the zero padding; fused input leaky-relu);
+//     the B operand of every tap is the same LDS rows read at a shifted column (bank-conflict free:
+//     32 consecutive floats per half-wave).  One barrier per chunk.
+//   * weights are repacked at load time to [tap][cin][cout] so the A operand is a coalesced 128-B row
+//     read straight from L2 (one float per lane per MFMA) through a buffer descriptor with the
+//     (tap, channel) part of the address in the scalar offset; A and B fragments ping-pong between two
+//     register sets so step s+1's operands are in flight under step s's 16 MFMAs.
+//   * bias, per-utterance conditioning, residual add, the WaveNet gate tanh*sigmoid, res/skip split
+//     and the flow's "x1 -= m" are epilogues on the accumulator registers -- no elementwise kernels,
+//     no extra HBM round trips.
 //   * ConvTranspose1d is polyphase: phase p of the output only touches taps k == p (mod stride),
 //     so it is the same kernel with tap_step = -1 and an output stride.
-// A plain VALU kernel (conv_generic) covers shapes the matrix cores cannot fill (Cin or Cout < 32,
-// depthwise, 63-tap single-channel FIRs).
+//   * launches that would not fill the chip (text encoder, flow, duration predictor at batch 1) go to
+//     a split-K sibling (conv_mfma_splitk_kernel): one output tile per workgroup, K split over up to
+//     16 waves, operands streamed from L2 through a register ring, no LDS staging.
+// A plain VALU kernel (conv_generic) covers what the matrix cores cannot fill (Cin < 32, depthwise) and
+// conv_cout1_kernel the long single-output-channel FIR at the end of HiFi-GAN (fused tanh + int16).
 #include "kernels.hpp"
 #include "devmath.hpp"
 #include <type_traits>
