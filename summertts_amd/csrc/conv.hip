@@ -531,7 +531,7 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
     const bool gate = a.epi == EPI_GATE;
     bool splitk = tile == 6 || tile == 7;
     int nw = tile == 7 ? 2 : 1;
-    if (tile < 0 || tile > 7) {
+    if (tile < 0 || tile > 9) {
         tile = pick_tile(a, nphase);
         const TileCfg& t = kTiles[tile];
         const int MT = 32 * t.MW * t.WM, NT = 32 * t.NW * t.WN;
@@ -543,6 +543,8 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
         else { if (nw == 2) launch_splitk<1, 2>(a, nphase, st); else launch_splitk<1, 1>(a, nphase, st); }
         return;
     }
+    if (tile == 8) { launch_mfma<1, 1, 1, 2>(a, nphase, st); return; }    // experiment: 32 x 64, 2 waves
+    if (tile == 9) { launch_mfma<2, 1, 1, 2>(a, nphase, st); return; }    // experiment: 64 x 64, 2 waves
     if (gate && kTiles[tile].MW != 2) tile = 3;
     switch (tile) {
         case 0: launch_mfma<2, 2, 2, 2>(a, nphase, st); break;
