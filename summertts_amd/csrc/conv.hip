@@ -102,10 +102,9 @@ constexpr int CK = 16;            // input channels staged per chunk
 constexpr int MAX_HALO = 64;
 
 template <int MW, int NW, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int mtiles) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtiles, const int b) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NTHR = WM * WN * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.z;
     const int orig_len = seg_len(a.in_seg, b);
     const int in_len = orig_len + (a.in_reflect ? 1 : 0);
     const int out_len = seg_len(a.out_seg, b);
@@ -219,8 +218,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
         if (last_tap) { nj = 0; nc = sc + 1; }
         if (s + 1 < nsteps) {
             load_a(nc, nj, anxt);
-            if (!last_tap) load_b(sc & 1, nj, bnxt);
-            else store_tile(nc & 1);          // chunk nc's tile (in registers since the start of chunk sc)
+            if (last_tap) {
+                // chunk boundary: this step's B fragment is already in registers, so the next tile can be
+                // published before this step's MFMAs issue; the next B fragment then has ONE load site
+                // (no phi copies between two differently-sourced register sets)
+                store_tile(nc & 1);          // chunk nc's tile (in registers since the start of chunk sc)
+                __syncthreads();             // tile nc visible to all waves; everyone is done reading tile sc
+                if (nc + 1 < nchunk) load_x(nc + 1);
+            }
+            load_b(nc & 1, nj, bnxt);
         }
 #pragma unroll
         for (int p = 0; p < CK / 2; p++)
@@ -229,11 +235,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
 #pragma unroll
                 for (int q = 0; q < NW; q++)
                     acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p][i], bcur[p][q], acc[i][q], 0, 0, 0);
-        if (last_tap && s + 1 < nsteps) {
-            __syncthreads();                  // tile nc visible to all waves; everyone is done reading tile sc
-            load_b(nc & 1, 0, bnxt);
-            if (nc + 1 < nchunk) load_x(nc + 1);
-        }
         sj = nj; sc = nc;
     };
     load_x(0);
@@ -295,6 +296,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int 
             }
         });
     });
+}
+
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int mtiles) {
+    conv_mfma_body<MW, NW, WM, WN>(a, mtiles, blockIdx.z);
+}
+
+// Grouped launch: up to kMaxGroup independent convs of identical geometry (the nResK ResBlock chains of
+// one decoder stage: same channels and length, different kernel size / dilation / weights / buffers) in
+// ONE grid.  blockIdx.z = group * B + utterance; the members are ordered longest K loop first, so the
+// short-K workgroups backfill the CUs the long ones still occupy, and one member's output drain
+// overlaps another member's MFMA phase.
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup G, int mtiles, int B) {
+    const int gi = blockIdx.z / B;
+    // G sits at offset 0 of the kernarg segment; indexing it through the segment pointer keeps the member
+    // selection a scalar load (indexing the by-value parameter would spill the whole struct to scratch)
+    (void)G;
+    const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    conv_mfma_body<MW, NW, WM, WN>(ga[gi], mtiles, blockIdx.z - gi * B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -524,6 +545,44 @@ static void launch_splitk(const ConvArgs& a, int nphase, hipStream_t st) {
     hipLaunchKernelGGL((conv_mfma_splitk_kernel<MW, NW>), grid, dim3(ks * 64), lds, st, a, mt);
 }
 
+template <int MW, int NW, int WM, int WN>
+static void launch_mfma_group(const ConvGroup& G, hipStream_t st) {
+    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
+    const ConvArgs& a = G.g[0];
+    int mt = (a.Cout_pad + MT - 1) / MT;
+    dim3 grid((a.max_n + NT - 1) / NT, mt, a.B * G.n);
+    constexpr int NTHR = WM * WN * 64;
+    size_t lds = (size_t)2 * CK * (((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR) * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_group_kernel<MW, NW, WM, WN>), grid, dim3(WM * WN * 64), lds, st, G, mt, a.B);
+}
+
+bool conv_group_eligible(const ConvGroup& G) {
+    if (G.n < 2 || G.n > kMaxGroup) return false;
+    const ConvArgs& r = G.g[0];
+    for (int i = 0; i < G.n; i++) {
+        const ConvArgs& a = G.g[i];
+        if (!conv_mfma_eligible(a) || a.transposed || a.epi == EPI_GATE) return false;
+        if (a.Cout_pad != r.Cout_pad || a.max_n != r.max_n || a.B != r.B) return false;
+    }
+    return true;
+}
+
+// tile: -1 automatic, 3 / 4 force 64x128 / 32x128
+void conv_mfma_group(const ConvGroup& Gin, hipStream_t st, int tile) {
+    ConvGroup G = Gin;
+    if (G.g[0].max_n <= 0 || G.g[0].B <= 0) return;
+    for (int i = 1; i < G.n; i++)                       // longest K loop first
+        for (int j = i; j > 0 && (long)G.g[j].ntap * G.g[j].Cin_pad > (long)G.g[j - 1].ntap * G.g[j - 1].Cin_pad; j--) {
+            ConvArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
+        }
+    if (tile != 3 && tile != 4) {
+        const ConvArgs& a = G.g[0];
+        const long nt = (a.max_n + 127) / 128;
+        tile = (a.Cout_pad % 64 == 0 && nt * (a.Cout_pad / 64) * a.B * G.n >= 1024) ? 3 : 4;
+    }
+    if (tile == 3) launch_mfma_group<2, 1, 1, 4>(G, st); else launch_mfma_group<1, 1, 1, 4>(G, st);
+}
+
 // mode: -1 automatic; 0..5 force an LDS-staged tile; 6 / 7 force the split-K kernel (NW = 1 / 2)
 void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
     int nphase = a.transposed ? a.out_stride : 1;
@@ -531,7 +590,7 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
     const bool gate = a.epi == EPI_GATE;
     bool splitk = tile == 6 || tile == 7;
     int nw = tile == 7 ? 2 : 1;
-    if (tile < 0 || tile > 9) {
+    if (tile < 0 || tile > 7) {
         tile = pick_tile(a, nphase);
         const TileCfg& t = kTiles[tile];
         const int MT = 32 * t.MW * t.WM, NT = 32 * t.NW * t.WN;
@@ -543,8 +602,6 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
         else { if (nw == 2) launch_splitk<1, 2>(a, nphase, st); else launch_splitk<1, 1>(a, nphase, st); }
         return;
     }
-    if (tile == 8) { launch_mfma<1, 1, 1, 2>(a, nphase, st); return; }    // experiment: 32 x 64, 2 waves
-    if (tile == 9) { launch_mfma<2, 1, 1, 2>(a, nphase, st); return; }    // experiment: 64 x 64, 2 waves
     if (gate && kTiles[tile].MW != 2) tile = 3;
     switch (tile) {
         case 0: launch_mfma<2, 2, 2, 2>(a, nphase, st); break;

@@ -85,7 +85,8 @@ bool Engine::ensure_pinned(size_t bytes) {
 void Engine::stage_begin(int s) { cur_stage_ = s; }
 void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); }
 
-void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o) {
+// builds the kernel arguments of one conv and books its FLOPs / minimum HBM bytes
+ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o, double* flops) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.x_ld = lin.ld; a.y = y; a.y_ld = lout.ld;
@@ -113,6 +114,13 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
         dec_bytes_ += 4.0 * ((double)c.Cin * lin.total + (double)c.Cout * lout.total + (double)wfl);
         if (o.res) dec_bytes_ += 4.0 * (double)c.Cout * lout.total;
     }
+    if (flops) *flops = fl;
+    return a;
+}
+
+void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o) {
+    double fl = 0;
+    const ConvArgs a = conv_args(c, x, lin, y, lout, o, &fl);
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
     if (can_mfma) {
         if (in_mfma_region_) { mfma_flops_ += fl; mfma_launches_++; }
@@ -425,43 +433,79 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         float* bup = reg;
         ConvOpt ou; ou.in_act = 1; ou.slope = 0.1f;
         conv(up, x, lx, bup, l2, ou);
-        // The nResK ResBlock chains only meet in the final sum (Generator_hifigan.cpp:159-173): run them
-        // concurrently on separate HIP streams so that a batch-1 stage (a few hundred workgroups per
-        // conv) keeps all 256 CUs busy and one chain's tail overlaps another chain's head.
+        // The nResK ResBlock chains only meet in the final sum (Generator_hifigan.cpp:159-173;
+        // /root/reference/src/modules/ResBlock1.cpp:55-69 per chain).
         const int nk = M.n_resk;
-        const bool fork = nk > 1 && nk <= 8;
-        if (fork) {
-            (void)hipEventRecord(ev_fork_, stream);
-            for (int k = 0; k < kAux; k++) (void)hipStreamWaitEvent(aux_[k], ev_fork_, 0);
-        }
         const float* outs[8];
-        int rank[8];                      // rank[j] = number of chains cheaper than chain j
-        for (int j = 0; j < nk && j < 8; j++) {
-            rank[j] = 0;
-            for (int q = 0; q < nk && q < 8; q++) {
-                const int kj = M.rb[(size_t)i * nk + j].c1[0].k, kq = M.rb[(size_t)i * nk + q].c1[0].k;
-                if (kq < kj || (kq == kj && q < j)) rank[j]++;
-            }
+        const int nd0 = nk > 0 ? (int)M.rb[(size_t)i * nk].c1.size() : 0;
+        bool grouped = conv_mode == 0 && nk >= 2 && nk <= kMaxGroup;
+        for (int j = 0; j < nk && grouped; j++) grouped = (int)M.rb[(size_t)i * nk + j].c1.size() == nd0;
+        if (grouped) {   // probe with layer 0 (geometry is the same for every layer of a chain)
+            ConvGroup G; G.n = nk;
+            const double f0 = flops_[3], b0 = dec_bytes_;
+            for (int j = 0; j < nk; j++) G.g[j] = conv_args(M.rb[(size_t)i * nk + j].c1[0], bup, l2, bup, l2, ConvOpt(), nullptr);
+            flops_[3] = f0; dec_bytes_ = b0;
+            grouped = conv_group_eligible(G);
         }
-        for (int j = 0; j < nk; j++) {   // /root/reference/src/modules/ResBlock1.cpp:55-69
-            const DResBlock& rb = M.rb[(size_t)i * nk + j];
-            float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce;
-            if (fork) cur_ = aux_[rank[j] % kAux];
-            const float* cur = bup;
-            const int nd = (int)rb.c1.size();
-            for (int d = 0; d < nd; d++) {
-                ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
-                conv(rb.c1[d], cur, l2, t1, l2, o1);
-                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur; o2.epi = EPI_RESADD;
-                float* nxt = (cur == pa) ? pb : pa;
-                conv(rb.c2[d], t1, l2, nxt, l2, o2);
-                cur = nxt;
+        if (grouped) {
+            // Layer d of ALL chains goes out as one grouped launch: 2 * nd launches per stage instead of
+            // 2 * nd * nResK, nResK times the workgroups per launch (a batch-1 stage otherwise yields only a
+            // few hundred), and chains of different kernel size backfill each other inside the grid.
+            const float* cur[kMaxGroup];
+            for (int j = 0; j < nk; j++) cur[j] = bup;
+            for (int d = 0; d < nd0; d++) {
+                ConvGroup G1, G2; G1.n = G2.n = nk;
+                double fl1 = 0, fl2 = 0, f = 0;
+                for (int j = 0; j < nk; j++) {
+                    const DResBlock& rb = M.rb[(size_t)i * nk + j];
+                    float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce;
+                    ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
+                    G1.g[j] = conv_args(rb.c1[d], cur[j], l2, t1, l2, o1, &f); fl1 += f;
+                    ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur[j]; o2.epi = EPI_RESADD;
+                    float* nxt = (cur[j] == pa) ? pb : pa;
+                    G2.g[j] = conv_args(rb.c2[d], t1, l2, nxt, l2, o2, &f); fl2 += f;
+                    cur[j] = nxt;
+                }
+                conv_mfma_group(G1, stream);
+                conv_mfma_group(G2, stream);
+                mfma_flops_ += fl1 + fl2; mfma_launches_ += 2;
             }
-            outs[j] = cur;
-        }
-        if (fork) {
-            for (int j = 0; j < nk && j < kAux; j++) { (void)hipEventRecord(ev_join_[j], aux_[j]); (void)hipStreamWaitEvent(stream, ev_join_[j], 0); }
-            cur_ = stream;
+            for (int j = 0; j < nk; j++) outs[j] = cur[j];
+        } else {
+            // fallback: the chains run concurrently on separate HIP streams
+            const bool fork = nk > 1 && nk <= 8;
+            if (fork) {
+                (void)hipEventRecord(ev_fork_, stream);
+                for (int k = 0; k < kAux; k++) (void)hipStreamWaitEvent(aux_[k], ev_fork_, 0);
+            }
+            int rank[8];                      // rank[j] = number of chains cheaper than chain j
+            for (int j = 0; j < nk && j < 8; j++) {
+                rank[j] = 0;
+                for (int q = 0; q < nk && q < 8; q++) {
+                    const int kj = M.rb[(size_t)i * nk + j].c1[0].k, kq = M.rb[(size_t)i * nk + q].c1[0].k;
+                    if (kq < kj || (kq == kj && q < j)) rank[j]++;
+                }
+            }
+            for (int j = 0; j < nk; j++) {
+                const DResBlock& rb = M.rb[(size_t)i * nk + j];
+                float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce;
+                if (fork) cur_ = aux_[rank[j] % kAux];
+                const float* cur = bup;
+                const int nd = (int)rb.c1.size();
+                for (int d = 0; d < nd; d++) {
+                    ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
+                    conv(rb.c1[d], cur, l2, t1, l2, o1);
+                    ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur; o2.epi = EPI_RESADD;
+                    float* nxt = (cur == pa) ? pb : pa;
+                    conv(rb.c2[d], t1, l2, nxt, l2, o2);
+                    cur = nxt;
+                }
+                outs[j] = cur;
+            }
+            if (fork) {
+                for (int j = 0; j < nk && j < kAux; j++) { (void)hipEventRecord(ev_join_[j], aux_[j]); (void)hipStreamWaitEvent(stream, ev_join_[j], 0); }
+                cur_ = stream;
+            }
         }
         // xs = ((rb_0 + rb_1) + ...) / nResK, written over the (now dead) upsampler output
         sum_scale(bup, outs, nk, (long)ce, stream);

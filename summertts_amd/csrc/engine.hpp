@@ -67,6 +67,7 @@ private:
     int fail(int code, const std::string& msg) { err_ = msg; return code; }
     bool ensure(Arena& a, size_t bytes);
     bool ensure_pinned(size_t bytes);
+    ConvArgs conv_args(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o, double* flops);
     void conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o);
     void ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu);
     void dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv);

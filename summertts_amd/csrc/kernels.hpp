@@ -77,6 +77,11 @@ struct AttnArgs {
 // eligible (caller then uses conv_generic).  `tile` < 0 picks a tile configuration heuristically.
 bool conv_mfma_eligible(const ConvArgs& a);
 void conv_mfma(const ConvArgs& a, hipStream_t st, int tile = -1);
+// several independent convs of identical geometry in one grid (decoder ResBlock chains of one stage)
+constexpr int kMaxGroup = 4;
+struct ConvGroup { ConvArgs g[kMaxGroup]; int n; };
+bool conv_group_eligible(const ConvGroup& G);
+void conv_mfma_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 void conv_generic(const ConvArgs& a, hipStream_t st);
 
 void embed(const int* ids, const float* emb, int vocab, int H, float scale, float* x, long ld, int total, hipStream_t st);
