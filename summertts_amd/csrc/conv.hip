@@ -102,17 +102,17 @@ constexpr int CK = 16;            // input channels staged per chunk
 constexpr int MAX_HALO = 64;
 
 template <int MW, int NW, int WM, int WN>
-__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtiles, const int b) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NTHR = WM * WN * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int orig_len = seg_len(a.in_seg, b);
     const int in_len = orig_len + (a.in_reflect ? 1 : 0);
     const int out_len = seg_len(a.out_seg, b);
     const int n_count = a.transposed ? in_len + a.n_extra : out_len;
-    const int n0 = blockIdx.x * NT;
+    const int n0 = bx * NT;
     if (n0 >= n_count) return;
-    const int phase = blockIdx.y / mtiles;
-    const int m0 = (blockIdx.y - phase * mtiles) * MT;
+    const int phase = by / mtiles;
+    const int m0 = (by - phase * mtiles) * MT;
     const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -121,7 +121,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
     const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
     const int lo = first < last ? first : last, hi = first < last ? last : first;
     const int W = NT + (hi - lo);      // staged window width (<= NT + MAX_HALO)
-    constexpr int ldsw = ((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR;   // every thread stores unconditionally
+    constexpr int WIN = NT + MAX_HALO;   // staged columns per row; thread t owns columns t, t + NTHR, ... < WIN
+    constexpr int ldsw = WIN;
     const int win0 = n0 + lo;
 
     const float* w = a.w + (size_t)phase * a.ntap * a.Cin_pad * a.Cout_pad;
@@ -191,7 +192,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
             const int ci = c * CK + r;
             const rsrc_t rs = make_rsrc(a.x + (size_t)ci * a.x_ld + in_base, ci < a.Cin ? (unsigned)orig_len * 4u : 0u);
 #pragma unroll
-            for (int i = 0; i < RI; i++) xr[r][i] = buf_load(rs, xoff[i]);   // raw: activation is applied at store time
+            for (int i = 0; i < RI; i++)
+                if ((i + 1) * NTHR <= WIN || tid < WIN - i * NTHR)   // partial last round: whole waves drop out
+                    xr[r][i] = buf_load(rs, xoff[i]);                // raw: activation is applied at store time
         }
     };
     auto store_tile = [&](int bufi) {      // registers (chunk loaded earlier) -> LDS buffer, fused input activation
@@ -200,9 +203,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
         for (int r = 0; r < CK; r++)
 #pragma unroll
             for (int i = 0; i < RI; i++) {
-                float v = xr[r][i];
-                if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
-                sb[r * ldsw + tid + i * NTHR] = v;
+                if ((i + 1) * NTHR <= WIN || tid < WIN - i * NTHR) {
+                    float v = xr[r][i];
+                    if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
+                    sb[r * ldsw + tid + i * NTHR] = v;
+                }
             }
     };
 
@@ -298,24 +303,48 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
     });
 }
 
+// Workgroup -> tile mapping, XCD-aware.  The grid is 1-D; hardware deals workgroup ids round-robin over the
+// 8 XCDs (id & 7), each with a private L2.  All `ny` row tiles (and transposed-conv phases) that read the
+// SAME input window are given to one XCD in consecutive dispatch slots, so the window is fetched from
+// HBM once and re-read from that XCD's L2; units (column tile x utterance x group member) are dealt
+// round-robin over the XCDs in launch order, which keeps the XCDs balanced when the members of a
+// grouped launch differ in K.
+struct TileId { int bx, by, bz; bool valid; };
+__device__ __forceinline__ TileId map_tile(int nx, int ny, int nz) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int ul = slot / ny;
+    TileId t;
+    t.by = slot - ul * ny;
+    const int unit = ul * 8 + xcd;
+    t.valid = unit < nx * nz;
+    t.bz = unit / nx;
+    t.bx = unit - t.bz * nx;
+    return t;
+}
+static inline unsigned mapped_grid(int nx, int ny, int nz) { return (unsigned)(((long)nx * nz + 7) / 8 * 8 * ny); }
+
 template <int MW, int NW, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int mtiles) {
-    conv_mfma_body<MW, NW, WM, WN>(a, mtiles, blockIdx.z);
+__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_kernel(ConvArgs a, int mtiles, int nx, int ny) {
+    const TileId t = map_tile(nx, ny, a.B);
+    if (!t.valid) return;
+    conv_mfma_body<MW, NW, WM, WN>(a, mtiles, t.bx, t.by, t.bz);
 }
 
 // Grouped launch: up to kMaxGroup independent convs of identical geometry (the nResK ResBlock chains of
 // one decoder stage: same channels and length, different kernel size / dilation / weights / buffers) in
-// ONE grid.  blockIdx.z = group * B + utterance; the members are ordered longest K loop first, so the
+// ONE grid.  z = group * B + utterance; the members are ordered longest K loop first, so the
 // short-K workgroups backfill the CUs the long ones still occupy, and one member's output drain
 // overlaps another member's MFMA phase.
 template <int MW, int NW, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup G, int mtiles, int B) {
-    const int gi = blockIdx.z / B;
+__global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
+    const TileId t = map_tile(nx, ny, B * G.n);
+    if (!t.valid) return;
+    const int gi = t.bz / B;
     // G sits at offset 0 of the kernarg segment; indexing it through the segment pointer keeps the member
     // selection a scalar load (indexing the by-value parameter would spill the whole struct to scratch)
-    (void)G;
     const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_mfma_body<MW, NW, WM, WN>(ga[gi], mtiles, blockIdx.z - gi * B);
+    conv_mfma_body<MW, NW, WM, WN>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -520,14 +549,10 @@ static int pick_tile(const ConvArgs& a, int nphase) {
 template <int MW, int NW, int WM, int WN>
 static void launch_mfma(const ConvArgs& a, int nphase, hipStream_t st) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
-    int mt = (a.Cout_pad + MT - 1) / MT;
-    int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
-    int halo = first < last ? last - first : first - last;
-    dim3 grid((a.max_n + NT - 1) / NT, mt * nphase, a.B);
-    constexpr int NTHR = WM * WN * 64;
-    size_t lds = (size_t)2 * CK * (((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR) * sizeof(float);   // double-buffered tile
-    (void)halo;
-    hipLaunchKernelGGL((conv_mfma_kernel<MW, NW, WM, WN>), grid, dim3(WM * WN * 64), lds, st, a, mt);
+    const int mt = (a.Cout_pad + MT - 1) / MT;
+    const int nx = (a.max_n + NT - 1) / NT, ny = mt * nphase;
+    size_t lds = (size_t)2 * CK * (NT + MAX_HALO) * sizeof(float);   // double-buffered tile
+    hipLaunchKernelGGL((conv_mfma_kernel<MW, NW, WM, WN>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * 64), lds, st, a, mt, nx, ny);
 }
 
 template <int MW, int NW>
@@ -549,11 +574,11 @@ template <int MW, int NW, int WM, int WN>
 static void launch_mfma_group(const ConvGroup& G, hipStream_t st) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     const ConvArgs& a = G.g[0];
-    int mt = (a.Cout_pad + MT - 1) / MT;
-    dim3 grid((a.max_n + NT - 1) / NT, mt, a.B * G.n);
-    constexpr int NTHR = WM * WN * 64;
-    size_t lds = (size_t)2 * CK * (((NT + MAX_HALO + NTHR - 1) / NTHR) * NTHR) * sizeof(float);
-    hipLaunchKernelGGL((conv_mfma_group_kernel<MW, NW, WM, WN>), grid, dim3(WM * WN * 64), lds, st, G, mt, a.B);
+    const int mt = (a.Cout_pad + MT - 1) / MT;
+    const int nx = (a.max_n + NT - 1) / NT;
+    size_t lds = (size_t)2 * CK * (NT + MAX_HALO) * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_group_kernel<MW, NW, WM, WN>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * 64), lds, st, G,
+                       mt, a.B, nx, mt);
 }
 
 bool conv_group_eligible(const ConvGroup& G) {
@@ -575,12 +600,17 @@ void conv_mfma_group(const ConvGroup& Gin, hipStream_t st, int tile) {
         for (int j = i; j > 0 && (long)G.g[j].ntap * G.g[j].Cin_pad > (long)G.g[j - 1].ntap * G.g[j - 1].Cin_pad; j--) {
             ConvArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
         }
-    if (tile != 3 && tile != 4) {
+    if (tile != 1 && tile != 3 && tile != 4 && tile != 5) {
         const ConvArgs& a = G.g[0];
         const long nt = (a.max_n + 127) / 128;
         tile = (a.Cout_pad % 64 == 0 && nt * (a.Cout_pad / 64) * a.B * G.n >= 1024) ? 3 : 4;
     }
-    if (tile == 3) launch_mfma_group<2, 1, 1, 4>(G, st); else launch_mfma_group<1, 1, 1, 4>(G, st);
+    switch (tile) {
+        case 1: launch_mfma_group<2, 2, 1, 4>(G, st); break;
+        case 3: launch_mfma_group<2, 1, 1, 4>(G, st); break;
+        case 5: launch_mfma_group<1, 2, 1, 4>(G, st); break;
+        default: launch_mfma_group<1, 1, 1, 4>(G, st); break;
+    }
 }
 
 // mode: -1 automatic; 0..5 force an LDS-staged tile; 6 / 7 force the split-K kernel (NW = 1 / 2)

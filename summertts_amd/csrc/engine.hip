@@ -466,8 +466,10 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     G2.g[j] = conv_args(rb.c2[d], t1, l2, nxt, l2, o2, &f); fl2 += f;
                     cur[j] = nxt;
                 }
-                conv_mfma_group(G1, stream);
-                conv_mfma_group(G2, stream);
+                static const char* gt = getenv("STS_GROUP_TILE");   // experiment knob: per-stage tile digits, e.g. "4335"
+                const int gtile = gt && (int)strlen(gt) > i ? gt[i] - '0' : -1;
+                conv_mfma_group(G1, stream, gtile);
+                conv_mfma_group(G2, stream, gtile);
                 mfma_flops_ += fl1 + fl2; mfma_launches_ += 2;
             }
             for (int j = 0; j < nk; j++) outs[j] = cur[j];

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def newest(pattern):
-    files = glob.glob(pattern)
+    files = glob.glob(pattern) + glob.glob(pattern.replace(os.sep + "*" + os.sep, os.sep))   # with or without the host sub-directory
     return max(files, key=os.path.getmtime)
 
 
@@ -28,7 +28,7 @@ def counter_sum(d, family):
     f = newest(os.path.join(d, "*", "*counter_collection.csv"))
     n, tot = 0, 0.0
     for r in csv.DictReader(open(f)):
-        if family in r["Kernel_Name"]:
+        if any(f in r["Kernel_Name"] for f in family):
             n += 1
             tot += float(r["Counter_Value"])
     return n, tot
@@ -40,11 +40,12 @@ def main():
     os.makedirs(out, exist_ok=True)
     st = newest(os.path.join(kt, "*", "*kernel_stats.csv"))
     shutil.copy(st, os.path.join(out, f"{tag}_kernel_stats.csv"))
-    fam = "conv_mfma_kernel"
-    rows = [r for r in csv.DictReader(open(st)) if fam in r["Name"]]
+    # the LDS-staged matrix-core conv, in its single (upsamplers) and grouped (ResBlock chains) launch forms
+    fam = ("conv_mfma_kernel", "conv_mfma_group_kernel")
+    rows = [r for r in csv.DictReader(open(st)) if any(f in r["Name"] for f in fam)]
     calls = sum(int(r["Calls"]) for r in rows)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
-    summary = {"tag": tag, "kernel_family": fam, "calls": calls, "avg_launch_us_rocprof": tot_ns / max(1, calls) / 1e3}
+    summary = {"tag": tag, "kernel_family": " + ".join(fam), "calls": calls, "avg_launch_us_rocprof": tot_ns / max(1, calls) / 1e3}
     if len(sys.argv) >= 6:
         nf, fetch_kb = counter_sum(sys.argv[3], fam)
         nw, write_kb = counter_sum(sys.argv[4], fam)
@@ -60,7 +61,7 @@ def main():
         f = newest(os.path.join(sys.argv[6], "*", "*counter_collection.csv"))
         disp = {}
         for r in csv.DictReader(open(f)):
-            if fam not in r["Kernel_Name"]:
+            if not any(f in r["Kernel_Name"] for f in fam):
                 continue
             d = disp.setdefault(r["Dispatch_Id"], {"t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
             d[r["Counter_Name"]] = float(r["Counter_Value"])
@@ -72,7 +73,7 @@ def main():
             "shader_clock_ghz": gui / tns if tns else None,
             "avg_launch_us_serialised": tns / max(1, len(disp)) / 1e3,
             "hbm_gbps_serialised": summary.get("hbm_bytes_per_launch_corrected", 0.0) / (tns / max(1, len(disp))) if tns else None,
-            "note_serialised": "rocprofv3 --pmc serialises dispatches: the three concurrent ResBlock chains run one after another here",
+            "note_serialised": "rocprofv3 --pmc serialises dispatches: dispatches run strictly one after another here",
         })
         json.dump(summary, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)
     json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
