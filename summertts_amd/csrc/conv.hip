@@ -98,6 +98,9 @@ __device__ __forceinline__ void epi_scalar(const ConvArgs& a, int row, size_t op
 // ------------------------------------------------------------------------------------------------
 // matrix-core kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef STS_EXP
+#define STS_EXP 0   // timing experiments only (tools/exp_build.sh); 0 in every shipped build
+#endif
 constexpr int CK = 16;            // input channels staged per chunk
 constexpr int MAX_HALO = 64;
 
@@ -186,24 +189,28 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
         xoff[i] = v ? (unsigned)src * 4u : kOOB;
     }
     float xr[CK][RI];
+    int sj = 0, sc = 0;   // tap / chunk of the current step
     auto load_x = [&](int c) {
+        if (STS_EXP & 1) { if (c > 0) return; }
 #pragma unroll
-        for (int r = 0; r < CK; r++) {
-            const int ci = c * CK + r;
-            const rsrc_t rs = make_rsrc(a.x + (size_t)ci * a.x_ld + in_base, ci < a.Cin ? (unsigned)orig_len * 4u : 0u);
+        for (int i = 0; i < RI; i++)
+            if ((i + 1) * NTHR <= WIN || tid < WIN - i * NTHR) {   // partial last round: whole waves drop out
 #pragma unroll
-            for (int i = 0; i < RI; i++)
-                if ((i + 1) * NTHR <= WIN || tid < WIN - i * NTHR)   // partial last round: whole waves drop out
-                    xr[r][i] = buf_load(rs, xoff[i]);                // raw: activation is applied at store time
-        }
+                for (int r = 0; r < CK; r++) {
+                    const int ci = c * CK + r;
+                    const rsrc_t rs = make_rsrc(a.x + (size_t)ci * a.x_ld + in_base, ci < a.Cin ? (unsigned)orig_len * 4u : 0u);
+                    xr[r][i] = buf_load(rs, xoff[i]);   // raw: activation is applied at store time
+                }
+            }
     };
     auto store_tile = [&](int bufi) {      // registers (chunk loaded earlier) -> LDS buffer, fused input activation
+        if (STS_EXP & 8) { if (bufi >= 0 && sc > 0) return; }
         float* sb = smem + bufi * (CK * ldsw);
 #pragma unroll
-        for (int r = 0; r < CK; r++)
+        for (int i = 0; i < RI; i++)
+            if ((i + 1) * NTHR <= WIN || tid < WIN - i * NTHR) {
 #pragma unroll
-            for (int i = 0; i < RI; i++) {
-                if ((i + 1) * NTHR <= WIN || tid < WIN - i * NTHR) {
+                for (int r = 0; r < CK; r++) {
                     float v = xr[r][i];
                     if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
                     sb[r * ldsw + tid + i * NTHR] = v;
@@ -211,27 +218,33 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
             }
     };
 
-    // ---- main loop over steps (chunk, tap), unrolled by two with ping-pong fragment buffers: while
-    // step s issues its MFMAs, the A fragment (L2) and the B fragment (LDS) of step s+1 are already in
-    // flight into the other buffer.  No register copies, no waits on the fresh loads.
-    float fa0[CK / 2][MW], fa1[CK / 2][MW], fb0[CK / 2][NW], fb1[CK / 2][NW];
-    int sc = 0, sj = 0;   // chunk / tap of the current step
-    auto do_step = [&](float (&acur)[CK / 2][MW], float (&anxt)[CK / 2][MW], float (&bcur)[CK / 2][NW],
+    // ---- main loop over steps (chunk, tap).  Fragment registers form rings indexed at compile time
+    // (the loop is unrolled by 6 = lcm(3, 2)): the A fragment (L2) of step s+2 and the B fragment (LDS) of
+    // step s+1 are in flight while step s issues its MFMAs.  The A ring is three deep for the sake of the
+    // INPUT prefetch: vmcnt retires in order, so a wait for an A fragment issued after the next chunk's
+    // input loads also waits for those (HBM latency); with distance 2 the first such wait comes three
+    // steps after the input loads were issued instead of one.
+    float fa[3][CK / 2][MW], fb[2][CK / 2][NW];
+    int aj = 0, ac = 0;   // tap / chunk of the next A fragment to request
+    auto request_a = [&](float (&dst)[CK / 2][MW]) {
+        if (!(STS_EXP & 2) || (ac == 0 && aj < 2)) load_a(ac, aj, dst);
+        if (++aj == a.ntap) { aj = 0; ac++; }
+    };
+    auto do_step = [&](float (&acur)[CK / 2][MW], float (&anew)[CK / 2][MW], float (&bcur)[CK / 2][NW],
                        float (&bnxt)[CK / 2][NW], int s) {
         const bool last_tap = sj + 1 == a.ntap;
         int nj = sj + 1, nc = sc;
         if (last_tap) { nj = 0; nc = sc + 1; }
+        if (s + 2 < nsteps) request_a(anew);
         if (s + 1 < nsteps) {
-            load_a(nc, nj, anxt);
             if (last_tap) {
                 // chunk boundary: this step's B fragment is already in registers, so the next tile can be
-                // published before this step's MFMAs issue; the next B fragment then has ONE load site
-                // (no phi copies between two differently-sourced register sets)
+                // published before this step's MFMAs issue
                 store_tile(nc & 1);          // chunk nc's tile (in registers since the start of chunk sc)
-                __syncthreads();             // tile nc visible to all waves; everyone is done reading tile sc
+                if (!(STS_EXP & 4)) __syncthreads();   // tile nc visible to all waves; everyone is done reading tile sc
                 if (nc + 1 < nchunk) load_x(nc + 1);
             }
-            load_b(nc & 1, nj, bnxt);
+            if (!(STS_EXP & 16)) load_b(nc & 1, nj, bnxt);
         }
 #pragma unroll
         for (int p = 0; p < CK / 2; p++)
@@ -243,19 +256,22 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
         sj = nj; sc = nc;
     };
     load_x(0);
+    request_a(fa[0]);
+    if (nsteps > 1) request_a(fa[1]);
     store_tile(0);
-    load_a(0, 0, fa0);
     __syncthreads();
-    load_b(0, 0, fb0);
+    load_b(0, 0, fb[0]);
     if (nchunk > 1) load_x(1);
-    for (int s = 0; s < nsteps; s += 2) {
-        do_step(fa0, fa1, fb0, fb1, s);
-        if (s + 1 < nsteps) do_step(fa1, fa0, fb1, fb0, s + 1);
-    }
+    for (int s = 0; s < nsteps; s += 6)
+        static_for<0, 6>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (s + u < nsteps) do_step(fa[u % 3], fa[(u + 2) % 3], fb[u % 2], fb[(u + 1) % 2], s + u);
+        });
 
     // ---- epilogue on the accumulator registers -------------------------------------------------
     // C/D layout of 32x32x2: col (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int out_off = a.out_off + phase;
+    if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
     if (a.epi == EPI_GATE) {
         if constexpr (MW == 2) {
             if (mvalid[0]) {

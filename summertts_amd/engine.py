@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsummertts_hip.so")
+LIB_PATH = os.environ.get("SUMMERTTS_HIP_LIB") or os.path.join(_HERE, "lib", "libsummertts_hip.so")   # override: kernel timing experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 
