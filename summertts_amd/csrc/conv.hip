@@ -364,6 +364,215 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup 
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused ResBlock layer for the narrow decoder stages (C = 32 * MW <= 64)
+//   y = x + conv2_{k2,d=1}( lrelu( conv1_{k1,d1}( lrelu(x) ) ) )        (ResBlock1.cpp:55-69, one dilation)
+// Timing experiments on MI355X (tools/exp_build.sh) showed that at these widths a third of a conv's
+// time is its output drain (22 MB written and flushed at kernel end for ~1-4 GFLOP of work).  Here a
+// workgroup produces a (C x NT) output tile from scratch: phase 1 computes the intermediate for the NT
+// columns plus conv2's halo (exactly 128 columns = 4 waves x 32) with the same staged-input K loop as
+// conv_mfma_body and parks it, biased and activated, in LDS; phase 2 runs conv2 straight out of that LDS
+// tile (no staging, no barrier in its K loop) and adds bias and the residual in the epilogue.  The
+// intermediate tensor, one launch and one kernel-end flush per layer disappear; the accumulation order
+// of both convs is the one of the unfused kernels, so results are bit-identical to them.
+// ------------------------------------------------------------------------------------------------
+constexpr int RL_W1 = 128;            // intermediate columns per workgroup
+constexpr int RL_XW = RL_W1 + 64;     // staged input window: W1 + 2 * h1, h1 = d1 (k1 - 1) / 2 <= 32
+
+template <int MW>
+__global__ __launch_bounds__(256) void resblock_layer_kernel(ResLayerGroup G, int nx) {
+    constexpr int C = 32 * MW, NTHR = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const t1 = smem;   // [C][RL_W1] (+ slack for masked columns); ALIASES the input staging buffers,
+                              // which are dead once phase 1 has issued its last MFMA (barrier below)
+    const TileId t = map_tile(nx, 1, G.B * G.n);
+    if (!t.valid) return;
+    const int gi = t.bz / G.B, b = t.bz - gi * G.B;
+    const ResLayerArgs& a = ((const ResLayerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[gi];
+    const int h1 = a.dil1 * (a.k1 - 1) / 2, h2 = (a.k2 - 1) / 2;
+    const int NT = RL_W1 - 2 * h2;                    // output columns of this workgroup
+    const int len = seg_len(G.seg, b);
+    const int n0 = t.bx * NT;
+    if (n0 >= len) return;
+    const size_t base = (size_t)seg_start(G.seg, b);
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    f32x16 acc[MW];
+#pragma unroll
+    for (int i = 0; i < MW; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    constexpr int nchunk = C / CK;
+    const unsigned a_voff = (unsigned)((half * C + l31) * 4);
+    float fa[3][CK / 2][MW], fb[2][CK / 2][1];
+    int sj, sc, aj, ac;
+
+    // ================= phase 1: t1 = lrelu(conv1(lrelu(x)) + b1) on columns [n0 - h2, n0 - h2 + 128) ==========
+    {
+        const rsrc_t wrs = make_rsrc(a.w1, (unsigned)(a.k1 * C * C * 4));
+        auto load_a = [&](int c, int j, float (&dst)[CK / 2][MW]) {
+            const unsigned sbase = (unsigned)(((j * C + c * CK) * C) * 4);
+#pragma unroll
+            for (int p = 0; p < CK / 2; p++)
+#pragma unroll
+                for (int i = 0; i < MW; i++)
+                    dst[p][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        wrs, (int)a_voff, (int)(sbase + (unsigned)(2 * p * C * 4 + i * 128)), 0));
+        };
+        auto load_b = [&](int bufi, int j, float (&dst)[CK / 2][1]) {
+            const float* sb = smem + bufi * (CK * RL_XW) + wn * 32 + l31 + j * a.dil1;
+#pragma unroll
+            for (int p = 0; p < CK / 2; p++) dst[p][0] = sb[(2 * p + half) * RL_XW];
+        };
+        const int win0 = n0 - h2 - h1;                // position of staged column 0
+        const bool stager = tid < RL_XW;              // waves 0..2 stage (192 columns)
+        unsigned xoff;
+        {
+            const int pos = win0 + tid;
+            xoff = (stager && tid < RL_W1 + 2 * h1 && pos >= 0 && pos < len) ? (unsigned)pos * 4u : kOOB;
+        }
+        float xr[CK];
+        auto load_x = [&](int c) {
+            if (stager) {
+#pragma unroll
+                for (int r = 0; r < CK; r++)
+                    xr[r] = buf_load(make_rsrc(a.x + (size_t)(c * CK + r) * G.ld + base, (unsigned)len * 4u), xoff);
+            }
+        };
+        auto store_tile = [&](int bufi) {
+            if (stager) {
+                float* sb = smem + bufi * (CK * RL_XW) + tid;
+#pragma unroll
+                for (int r = 0; r < CK; r++) { float v = xr[r]; sb[r * RL_XW] = v < 0.f ? v * G.slope : v; }
+            }
+        };
+        const int nsteps = nchunk * a.k1;
+        sj = 0; sc = 0; aj = 0; ac = 0;
+        auto request_a = [&](float (&dst)[CK / 2][MW]) {
+            load_a(ac, aj, dst);
+            if (++aj == a.k1) { aj = 0; ac++; }
+        };
+        auto do_step = [&](float (&acur)[CK / 2][MW], float (&anew)[CK / 2][MW], float (&bcur)[CK / 2][1],
+                           float (&bnxt)[CK / 2][1], int s) {
+            const bool last_tap = sj + 1 == a.k1;
+            int nj = sj + 1, nc = sc;
+            if (last_tap) { nj = 0; nc = sc + 1; }
+            if (s + 2 < nsteps) request_a(anew);
+            if (s + 1 < nsteps) {
+                if (last_tap) {
+                    store_tile(nc & 1);
+                    __syncthreads();
+                    if (nc + 1 < nchunk) load_x(nc + 1);
+                }
+                load_b(nc & 1, nj, bnxt);
+            }
+#pragma unroll
+            for (int p = 0; p < CK / 2; p++)
+#pragma unroll
+                for (int i = 0; i < MW; i++)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p][i], bcur[p][0], acc[i], 0, 0, 0);
+            sj = nj; sc = nc;
+        };
+        load_x(0);
+        request_a(fa[0]);
+        if (nsteps > 1) request_a(fa[1]);
+        store_tile(0);
+        __syncthreads();
+        load_b(0, 0, fb[0]);
+        if (nchunk > 1) load_x(1);
+        for (int s = 0; s < nsteps; s += 6)
+            static_for<0, 6>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if (s + u < nsteps) do_step(fa[u % 3], fa[(u + 2) % 3], fb[u % 2], fb[(u + 1) % 2], s + u);
+            });
+    }
+    // park the intermediate: bias, conv2's input activation, conv2's zero padding outside [0, len)
+    __syncthreads();          // every wave is done reading the staged input (t1 overwrites it)
+    {
+        const int col = wn * 32 + l31;
+        const int pos = n0 - h2 + col;
+        const bool inside = pos >= 0 && pos < len;
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[i][r];
+                if (a.b1) v += a.b1[row];
+                v = v < 0.f ? v * G.slope : v;
+                t1[row * RL_W1 + col] = inside ? v : 0.f;
+                acc[i][r] = 0.f;
+            });
+        });
+    }
+    __syncthreads();
+
+    // ================= phase 2: y = conv2(t1) + b2 + x on columns [n0, n0 + NT) ==============================
+    {
+        const rsrc_t wrs = make_rsrc(a.w2, (unsigned)(a.k2 * C * C * 4));
+        auto load_a = [&](int c, int j, float (&dst)[CK / 2][MW]) {
+            const unsigned sbase = (unsigned)(((j * C + c * CK) * C) * 4);
+#pragma unroll
+            for (int p = 0; p < CK / 2; p++)
+#pragma unroll
+                for (int i = 0; i < MW; i++)
+                    dst[p][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        wrs, (int)a_voff, (int)(sbase + (unsigned)(2 * p * C * 4 + i * 128)), 0));
+        };
+        auto load_b = [&](int c, int j, float (&dst)[CK / 2][1]) {
+            const float* sb = t1 + (c * CK) * RL_W1 + wn * 32 + l31 + j;
+#pragma unroll
+            for (int p = 0; p < CK / 2; p++) dst[p][0] = sb[(2 * p + half) * RL_W1];
+        };
+        const int nsteps = nchunk * a.k2;
+        sj = 0; sc = 0; aj = 0; ac = 0;
+        auto request_a = [&](float (&dst)[CK / 2][MW]) {
+            load_a(ac, aj, dst);
+            if (++aj == a.k2) { aj = 0; ac++; }
+        };
+        auto do_step = [&](float (&acur)[CK / 2][MW], float (&anew)[CK / 2][MW], float (&bcur)[CK / 2][1],
+                           float (&bnxt)[CK / 2][1], int s) {
+            int nj = sj + 1, nc = sc;
+            if (nj == a.k2) { nj = 0; nc = sc + 1; }
+            if (s + 2 < nsteps) request_a(anew);
+            if (s + 1 < nsteps) load_b(nc, nj, bnxt);
+#pragma unroll
+            for (int p = 0; p < CK / 2; p++)
+#pragma unroll
+                for (int i = 0; i < MW; i++)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p][i], bcur[p][0], acc[i], 0, 0, 0);
+            sj = nj; sc = nc;
+        };
+        request_a(fa[0]);
+        if (nsteps > 1) request_a(fa[1]);
+        load_b(0, 0, fb[0]);
+        for (int s = 0; s < nsteps; s += 6)
+            static_for<0, 6>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if (s + u < nsteps) do_step(fa[u % 3], fa[(u + 2) % 3], fb[u % 2], fb[(u + 1) % 2], s + u);
+            });
+    }
+    {
+        const int col = wn * 32 + l31;
+        const int pos = n0 + col;
+        if (col < NT && pos < len) {
+            const size_t opos = base + (size_t)pos;
+            static_for<0, MW>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][r];
+                    if (a.b2) v += a.b2[row];
+                    a.y[(size_t)row * G.ld + opos] = v + a.x[(size_t)row * G.ld + opos];
+                });
+            });
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // split-K matrix-core kernel for LATENCY-bound shapes (batch-1 text encoder / flow / duration
 // predictor: N = 128..700 positions, a few dozen output tiles, K up to 2304).  The LDS-staged kernel
 // above would run such a conv on a handful of CUs as one long dependent chain of global-load round
@@ -595,6 +804,36 @@ static void launch_mfma_group(const ConvGroup& G, hipStream_t st) {
     size_t lds = (size_t)2 * CK * (NT + MAX_HALO) * sizeof(float);
     hipLaunchKernelGGL((conv_mfma_group_kernel<MW, NW, WM, WN>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * 64), lds, st, G,
                        mt, a.B, nx, mt);
+}
+
+bool resblock_layer_eligible(const ResLayerGroup& G) {
+    if (G.n < 1 || G.n > kMaxGroup || (G.C != 32 && G.C != 64) || G.max_n <= 0 || G.B <= 0) return false;
+    for (int i = 0; i < G.n; i++) {
+        const ResLayerArgs& a = G.g[i];
+        if (!(a.k1 & 1) || !(a.k2 & 1) || a.k1 < 1 || a.k2 < 1) return false;
+        if (a.dil1 * (a.k1 - 1) > RL_XW - RL_W1 || a.k2 - 1 > 32) return false;
+        if (a.x == a.y) return false;
+    }
+    return true;
+}
+
+void resblock_layer(const ResLayerGroup& Gin, hipStream_t st) {
+    ResLayerGroup G = Gin;
+    for (int i = 1; i < G.n; i++)                       // longest K loops first
+        for (int j = i; j > 0 && G.g[j].k1 + G.g[j].k2 > G.g[j - 1].k1 + G.g[j - 1].k2; j--) {
+            ResLayerArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
+        }
+    int nx = 0;
+    for (int i = 0; i < G.n; i++) {
+        const int NT = RL_W1 - (G.g[i].k2 - 1);
+        const int n = (G.max_n + NT - 1) / NT;
+        if (n > nx) nx = n;
+    }
+    const size_t stage = (size_t)2 * CK * RL_XW, park = (size_t)G.C * RL_W1 + 64;
+    const size_t lds = (stage > park ? stage : park) * sizeof(float);
+    const dim3 grid(mapped_grid(nx, 1, G.B * G.n));
+    if (G.C == 32) hipLaunchKernelGGL((resblock_layer_kernel<1>), grid, dim3(256), lds, st, G, nx);
+    else hipLaunchKernelGGL((resblock_layer_kernel<2>), grid, dim3(256), lds, st, G, nx);
 }
 
 bool conv_group_eligible(const ConvGroup& G) {

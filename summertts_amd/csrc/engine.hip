@@ -453,7 +453,39 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
             // few hundred), and chains of different kernel size backfill each other inside the grid.
             const float* cur[kMaxGroup];
             for (int j = 0; j < nk; j++) cur[j] = bup;
+            static const bool no_fuse = getenv("STS_NO_FUSE") != nullptr;   // experiment knob
             for (int d = 0; d < nd0; d++) {
+                // narrow stages: the whole layer (conv1 -> lrelu -> conv2 -> + x) of all chains in one launch
+                ResLayerGroup R;
+                memset(&R, 0, sizeof(R));
+                R.n = nk; R.C = up.Cout; R.ld = l2.ld; R.slope = 0.1f; R.seg = l2.seg; R.B = l2.nb; R.max_n = l2.max_len;
+                bool fuse = !no_fuse;
+                for (int j = 0; j < nk && fuse; j++) {
+                    const DResBlock& rb = M.rb[(size_t)i * nk + j];
+                    const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
+                    fuse = c1.Cin == R.C && c1.Cout == R.C && c2.Cin == R.C && c2.Cout == R.C && c1.Cin_pad == R.C &&
+                           c1.Cout_pad == R.C && c2.Cin_pad == R.C && c2.Cout_pad == R.C && !c1.depthwise && !c2.depthwise &&
+                           !c1.transposed && !c2.transposed && c2.dil == 1 && c1.pad == c1.dil * (c1.k - 1) / 2 &&
+                           c2.pad == (c2.k - 1) / 2;
+                    float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce;
+                    float* nxt = (cur[j] == pa) ? pb : pa;
+                    R.g[j].x = cur[j]; R.g[j].y = nxt; R.g[j].w1 = c1.w; R.g[j].b1 = c1.bias; R.g[j].w2 = c2.w; R.g[j].b2 = c2.bias;
+                    R.g[j].k1 = c1.k; R.g[j].dil1 = c1.dil; R.g[j].k2 = c2.k;
+                }
+                if (fuse && resblock_layer_eligible(R)) {
+                    double fl = 0, f = 0;
+                    for (int j = 0; j < nk; j++) {   // book FLOPs / algorithmic bytes exactly as for the two separate convs
+                        const DResBlock& rb = M.rb[(size_t)i * nk + j];
+                        ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
+                        (void)conv_args(rb.c1[d], cur[j], l2, R.g[j].y, l2, o1, &f); fl += f;
+                        ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur[j]; o2.epi = EPI_RESADD;
+                        (void)conv_args(rb.c2[d], cur[j], l2, R.g[j].y, l2, o2, &f); fl += f;
+                        cur[j] = R.g[j].y;
+                    }
+                    resblock_layer(R, stream);
+                    mfma_flops_ += fl; mfma_launches_ += 1;
+                    continue;
+                }
                 ConvGroup G1, G2; G1.n = G2.n = nk;
                 double fl1 = 0, fl2 = 0, f = 0;
                 for (int j = 0; j < nk; j++) {

@@ -80,6 +80,20 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile = -1);
 // several independent convs of identical geometry in one grid (decoder ResBlock chains of one stage)
 constexpr int kMaxGroup = 4;
 struct ConvGroup { ConvArgs g[kMaxGroup]; int n; };
+// One ResBlock1 layer, x + conv2(lrelu(conv1_dilated(lrelu(x)))), as ONE kernel for narrow stages
+// (C = 32 / 64): the intermediate never leaves the CU (LDS).  Up to kMaxGroup chains per grid.
+struct ResLayerArgs {
+    const float* x; float* y;                 // [C][ld], distinct buffers
+    const float *w1, *b1, *w2, *b2;           // packed [k][C][C] (cout contiguous), biases may be null
+    int k1, dil1, k2;
+};
+struct ResLayerGroup {
+    ResLayerArgs g[kMaxGroup];                // must stay the first member (indexed through the kernarg pointer)
+    int n, C; long ld; float slope;
+    SegView seg; int B; int max_n;
+};
+bool resblock_layer_eligible(const ResLayerGroup& G);
+void resblock_layer(const ResLayerGroup& G, hipStream_t st);
 bool conv_group_eligible(const ConvGroup& G);
 void conv_mfma_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 void conv_generic(const ConvArgs& a, hipStream_t st);
