@@ -228,7 +228,7 @@ def main():
             },
             "stage_ms_per_step": {k: float(v / args.steps) for k, v in zip(("text_encoder", "duration", "flow", "decoder"), stage_ms)},
             "roofline": {
-                "kernel": "conv_mfma_kernel + conv_mfma_group_kernel (decoder upsamplers + grouped ResBlock convs, v_mfma_f32_32x32x2_f32)",
+                "kernel": "conv_mfma_kernel + conv_mfma_group_kernel + resblock_layer_kernel (decoder upsamplers + grouped / fused ResBlock convs, v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma",
                 "achieved": achieved_tf,
                 "peak": PEAK_F32_MFMA_TFLOPS,
