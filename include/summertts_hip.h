@@ -59,6 +59,21 @@ int sts_get_info(const sts_engine* e, sts_model_info* info);
 int sts_infer_ids(sts_engine* e, const int32_t* ids, int32_t n, int32_t sid, float length_scale,
                   int16_t** pcm_out, int32_t* n_out);
 
+/* Streaming form (no reference counterpart: SynthesizerTrn::infer returns the whole utterance,
+ * SynthesizerTrn.cpp:389-400).  Text encoder, duration predictor and flow run once; the decoder then runs
+ * chunk by chunk (chunk_frames acoustic frames each, decoded with the receptive-field halo on both sides) and
+ * `cb` receives every chunk's PCM as soon as it is on the host: first audio after one chunk instead of after
+ * the whole utterance, decoder workspace bounded by the chunk size.  The concatenated chunks equal
+ * sts_infer_ids' output bit for bit when the kernel variant is pinned (sts_set_conv_mode) and to within 1 LSB
+ * under the automatic choice (a chunk is a smaller launch and may be routed to the split-K kernel, which sums
+ * K in a different order).  `pcm` is only valid during the callback; a non-zero return stops the stream.
+ * *n_total = samples delivered. */
+typedef int (*sts_chunk_cb)(void* user, const int16_t* pcm, int32_t n_samples, int32_t sample_offset);
+int sts_infer_ids_stream(sts_engine* e, const int32_t* ids, int32_t n, int32_t sid, float length_scale,
+                         int32_t chunk_frames, sts_chunk_cb cb, void* user, int32_t* n_total);
+/* frames of context the streaming decoder adds on each side of a chunk (a property of the loaded model) */
+int sts_stream_halo_frames(const sts_engine* e);
+
 /* Batched form (new capability; the reference processes exactly one utterance per call).  The B
  * utterances are packed along time on the device and run through every kernel together.
  * pcm_out[b] is malloc()'d per utterance. */

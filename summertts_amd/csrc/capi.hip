@@ -104,6 +104,22 @@ int sts_infer_ids(sts_engine* e, const int32_t* ids, int32_t n, int32_t sid, flo
     return sts_infer_ids_batch(e, 1, idp, &n, &sid, &length_scale, pcm_out, n_out);
 }
 
+int sts_infer_ids_stream(sts_engine* e, const int32_t* ids, int32_t n, int32_t sid, float length_scale, int32_t chunk_frames,
+                         sts_chunk_cb cb, void* user, int32_t* n_total) {
+    if (!e || !ids || !cb) return set_err(STS_EINVAL, "null argument");
+    const int32_t* idp[1] = {ids};
+    StreamSpec ss{chunk_frames, cb, user};
+    const int rc = e->eng.run(1, idp, &n, &sid, &length_scale, &ss);
+    if (rc != STS_OK) return set_err(rc, e->eng.error());
+    if (n_total) *n_total = (int32_t)e->eng.total_samples;
+    return STS_OK;
+}
+
+int sts_stream_halo_frames(const sts_engine* e) {
+    if (!e) return set_err(STS_EINVAL, "null engine");
+    return decoder_halo_frames(e->eng.model);
+}
+
 int sts_set_forced_durations(sts_engine* e, const int32_t* dur, int64_t count) {
     if (!e) return set_err(STS_EINVAL, "null engine");
     if (!dur || count <= 0) { e->eng.have_forced = false; return STS_OK; }

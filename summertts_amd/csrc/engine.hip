@@ -6,6 +6,7 @@
 // data-dependent frame count F (SynthesizerTrn.cpp:376-381).
 #include "engine.hpp"
 
+#include <algorithm>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -168,6 +169,28 @@ void Engine::tap(const char* name, const float* d, int channels, long ld, long l
                       (size_t)length * sizeof(float), (size_t)channels, hipMemcpyDeviceToHost);
 }
 
+
+// Frames of z (per side) that influence one output sample through the decoder: conv_pre, every upsampler,
+// the widest ResBlock chain of every stage, and the tail.  Conservative (rounded up at every level).
+int decoder_halo_frames(const Model& M) {
+    double R = M.dec_type == 0 ? (M.conv_post.k - 1) / 2 : (M.conv_post.k - 1) / 2 + 12;   // tail: reflect pad, iSTFT overlap, synthesis FIR
+    const int nk = M.n_resk;
+    for (int i = M.n_up - 1; i >= 0; i--) {
+        double rb = 0;
+        for (int j = 0; j < nk; j++) {
+            const DResBlock& b = M.rb[(size_t)i * nk + j];
+            double r = 0;
+            for (size_t d = 0; d < b.c1.size(); d++) r += b.c1[d].dil * (b.c1[d].k - 1) / 2 + b.c2[d].dil * (b.c2[d].k - 1) / 2;
+            if (r > rb) rb = r;
+        }
+        R += rb;
+        const DConv& up = M.ups[i];
+        R = ceil((R + up.k) / (double)up.stride) + 1;     // through the transposed conv (kernel k, stride s)
+    }
+    R += (M.conv_pre.k - 1) / 2;
+    return (int)ceil(R) + 1;
+}
+
 struct BufT {
     int *meta_i; float* ls; int* ids; int* forced;
     float *x, *qkv, *att, *y, *x1, *ffh, *m;
@@ -180,9 +203,10 @@ struct BufF {
     int16_t* pcm;
 };
 
-int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls) {
+int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss) {
     Model& M = model;
     if (B <= 0 || !ids || !n) return fail(STS_EINVAL, "empty batch");
+    if (ss && (B != 1 || ss->chunk_frames <= 0 || !ss->cb)) return fail(STS_EINVAL, "streaming takes one utterance, a positive chunk size and a callback");
     HIPCK(hipSetDevice(device));
     taps.clear();
     memset(&prof, 0, sizeof(prof));
@@ -211,7 +235,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     BufT bt;
     auto layoutT = [&](Arena& A) {
         A.used = 0;
-        bt.meta_i = A.get<int>((size_t)7 * B + 8);
+        bt.meta_i = A.get<int>((size_t)9 * B + 8);
         bt.ls = A.get<float>(B);
         bt.ids = A.get<int>(Ttot);
         bt.forced = A.get<int>(Ttot);
@@ -236,7 +260,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     arenaT_.measuring = false; layoutT(arenaT_);
 
     // ---------------- one H2D: geometry + ids (+ forced durations)
-    const size_t meta_ints = (size_t)7 * B + 8;
+    const size_t meta_ints = (size_t)9 * B + 8;
     const size_t up_bytes = (meta_ints + B + 2 * (size_t)Ttot) * 4 + 1024;
     if (!ensure_pinned(up_bytes + ((size_t)Ttot + B) * 4)) return fail(STS_EDEVICE, "pinned host allocation failed");
     int* pm = (int*)pinned_;
@@ -347,16 +371,23 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     }
     const int hop = M.hop_total;
     if ((double)Ftot * hop > 2.0e9 || (double)Ftot * hop * 8 > 6.0e10) return fail(STS_EINVAL, "batch produces too many samples for one call");
-    HIPCK(hipMemcpyAsync(d_offF, p_offF, (size_t)2 * B * 4, hipMemcpyHostToDevice, stream));
+    {   // frame geometry + (normal call) the decode windows = the utterances, in the same copy
+        int* pw = pm + 5 * B + 2;
+        for (int b = 0; b < B; b++) { pw[b] = p_offF[b]; pw[B + b] = p_offF[b]; pw[2 * B + b] = p_lenF[b]; }
+        HIPCK(hipMemcpyAsync(d_offF, p_offF, (size_t)(5 * B + 2) * 4, hipMemcpyHostToDevice, stream));
+    }
 
-    // ---------------- frame-level workspace
+    // ---------------- frame-level workspace.  The flow works on all Ftot frames; the decoder works on
+    // "windows" of z: whole utterances normally (Wcap == Ftot), one chunk plus its two halos when streaming.
+    const int halo = decoder_halo_frames(M);
+    const long Wcap = ss ? std::min<long>(Ftot, (long)ss->chunk_frames + 2 * halo) : Ftot;
     int upS = 1;
     for (int u : M.up_rate) upS *= u;
     std::vector<size_t> stage_elems(M.n_up);
     size_t regA = 0, regB = 0;
-    { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)(1 + 3 * M.n_resk) * M.ups[i].Cout * Ftot * S;
+    { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)(1 + 3 * M.n_resk) * M.ups[i].Cout * Wcap * S;
           if (i & 1) { if (stage_elems[i] > regB) regB = stage_elems[i]; } else { if (stage_elems[i] > regA) regA = stage_elems[i]; } } }
-    const long Lsb = Ftot * upS + B;           // MB-iSTFT: frames + 1 per utterance
+    const long Lsb = Wcap * upS + B;           // MB-iSTFT: frames + 1 per window
     const int sbC = M.conv_post.Cout;
     BufF bf;
     auto layoutF = [&](Arena& A) {
@@ -364,25 +395,20 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         bf.z = A.get<float>((size_t)C * Ftot); bf.h = A.get<float>((size_t)wnH * Ftot);
         bf.acts = A.get<float>((size_t)wnH * Ftot); bf.out = A.get<float>((size_t)wnH * Ftot);
         bf.fliptmp = A.get<float>((M.n_flows & 1) ? (size_t)C * Ftot : 1);
-        bf.x0 = A.get<float>((size_t)M.up_init * Ftot);
+        bf.x0 = A.get<float>((size_t)M.up_init * Wcap);
         bf.regA = A.get<float>(regA + 1); bf.regB = A.get<float>(regB + 1);
         if (M.dec_type != 0) {
             bf.tailA = A.get<float>((size_t)sbC * Lsb); bf.tailB = A.get<float>((size_t)sbC * Lsb);
-            bf.tailC = A.get<float>((size_t)4 * Ftot * upS * 4);
+            bf.tailC = A.get<float>((size_t)4 * Wcap * upS * 4);
         } else { bf.tailA = bf.tailB = bf.tailC = nullptr; }
-        bf.wave = A.get<float>(record_taps ? (size_t)Ftot * hop : 1);
-        bf.pcm = A.get<int16_t>((size_t)Ftot * hop);
+        bf.wave = A.get<float>(record_taps ? (size_t)Wcap * hop : 1);
+        bf.pcm = A.get<int16_t>((size_t)Wcap * hop);
     };
     arenaF_.measuring = true; layoutF(arenaF_);
     if (!ensure(arenaF_, arenaF_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (frame-level workspace)");
     arenaF_.measuring = false; layoutF(arenaF_);
 
-    auto lvF = [&](int scale, int extra) {
-        Lvl l; l.seg = SegView{d_offF, d_lenF, scale, extra}; l.nb = B; l.max_len = maxF * scale + extra;
-        l.total = Ftot * scale + (long)B * extra; l.ld = l.total;
-        return l;
-    };
-    const Lvl lv1 = lvF(1, 0);
+    Lvl lv1; lv1.seg = SegView{d_offF, d_lenF, 1, 0}; lv1.nb = B; lv1.max_len = maxF; lv1.total = Ftot; lv1.ld = Ftot;
     mark(7);
     // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
     stage_begin(2);
@@ -413,15 +439,27 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     mark(3);
 
     // ---------------- decoder trunk (Generator_hifigan.cpp:139-175 and the identical loops of MS/Istft/MBB)
+    // One decode pass over `nw` windows of z.  Window w covers frames [zoff[w], zoff[w] + wlen[w]) of the packed z
+    // and owns the compact range starting at coff[w] in every decoder buffer.  (Normal call: the windows ARE the
+    // utterances and zoff == coff == offF.)  d_win = device ints {zoff[nw], coff[nw], wlen[nw]}.
     stage_begin(3);
+    int* const d_win = bt.meta_i + 5 * B + 2;
+    auto decode = [&](int nw, long Wtot, int maxW) -> int {
+    auto lvF = [&](int scale, int extra) {
+        Lvl l; l.seg = SegView{d_win + nw, d_win + 2 * nw, scale, extra}; l.nb = nw; l.max_len = maxW * scale + extra;
+        l.total = Wtot * scale + (long)nw * extra; l.ld = l.total;
+        return l;
+    };
+    Lvl lz; lz.seg = SegView{d_win, d_win + 2 * nw, 1, 0}; lz.nb = nw; lz.max_len = maxW; lz.total = Ftot; lz.ld = Ftot;
+    const Lvl lw1 = lvF(1, 0);
     {
         ConvOpt op;
         if (M.dec_type == 0 && ms) { conv(M.dec_cond, bt.g, lvB, bt.cond_dec, lvB, ConvOpt()); op.ubias = bt.cond_dec; }
-        conv(M.conv_pre, bf.z, lv1, bf.x0, lv1, op);
+        conv(M.conv_pre, bf.z, lz, bf.x0, lw1, op);
     }
     const float* x = bf.x0;
     int S = 1;
-    Lvl lx = lv1;
+    Lvl lx = lw1;
     mark(5);
     in_mfma_region_ = true;
     for (int i = 0; i < M.n_up; i++) {
@@ -550,7 +588,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
 
     // ---------------- decoder tail
     float* wave = record_taps ? bf.wave : nullptr;
-    const long Ntot = Ftot * hop;
+    const long Ntot = Wtot * hop;
     if (M.dec_type == 0) {          // Generator_hifigan.cpp:177-179 + SynthesizerTrn.cpp:389-396
         ConvOpt o; o.in_act = 1; o.slope = 1e-2f; o.epi = EPI_TANH_PCM; o.pcm = bf.pcm; o.aux = wave;
         conv(M.conv_post, x, lx, nullptr, lx, o);
@@ -562,26 +600,60 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         const int bands = M.dec_type == 2 ? 1 : 4;
         const Lvl ltm = lvF(S * 4, 0);
         float* tm = bf.tailC;
-        istft_ola(bf.tailB, lsb.ld, bands, 18, lsb.seg, tm, ltm.ld, ltm.seg, B, ltm.max_len, stream);
+        istft_ola(bf.tailB, lsb.ld, bands, 18, lsb.seg, tm, ltm.ld, ltm.seg, nw, ltm.max_len, stream);
         if (M.dec_type == 2) {
             quantize_pcm(tm, bf.pcm, Ntot, stream);
             if (wave) HIPCK(hipMemcpyAsync(wave, tm, (size_t)Ntot * 4, hipMemcpyDeviceToDevice, stream));
         } else {
             const Lvl lo = lvF(S * 16, 0);
-            synth_fir(tm, ltm.ld, ltm.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, wave, bf.pcm, lo.seg, B,
+            synth_fir(tm, ltm.ld, ltm.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, wave, bf.pcm, lo.seg, nw,
                       ltm.max_len, stream);
         }
         flops_[3] += 2.0 * (double)Ntot * (16.0 * 4 + 4 * 18 * 4 / 4.0);
     }
     mark(4);
     if (wave) tap("wave", wave, 1, Ntot, Ntot);
+    return STS_OK;
+    };   // decode
 
-    d_pcm = bf.pcm;
-    total_samples = Ntot;
     n_samples.resize(B);
     for (int b = 0; b < B; b++) n_samples[b] = p_lenF[b] * hop;
-    HIPCK(hipStreamSynchronize(stream));
-    HIPCK(hipGetLastError());
+    if (!ss) {
+        const int rc = decode(B, Ftot, maxF);   // windows = utterances (uploaded with the frame geometry)
+        if (rc != STS_OK) return rc;
+        d_pcm = bf.pcm;
+        total_samples = Ftot * hop;
+        HIPCK(hipStreamSynchronize(stream));
+        HIPCK(hipGetLastError());
+    } else {
+        // Streaming: chunk c = frames [f0, f1) is decoded from the window [f0 - halo, f1 + halo)
+        // clipped to the utterance; the halo covers the decoder's receptive field, so the kept samples are
+        // computed from exactly the inputs the one-pass decode sees (bit-identical for a pinned kernel variant).  PCM of a chunk goes to the caller before the next chunk starts.
+        if (ms && M.dec_type == 0 && B != 1) return fail(STS_EINVAL, "streaming is single-utterance");
+        const long F = Ftot;
+        int16_t* hp = nullptr;
+        const size_t hp_off = (up_bytes + ((size_t)Ttot + B) * 4 + 255) & ~(size_t)255;
+        if (!ensure_pinned(hp_off + (size_t)ss->chunk_frames * hop * 2 + 256)) return fail(STS_EDEVICE, "pinned host allocation failed");
+        pm = (int*)pinned_;
+        hp = (int16_t*)(pinned_ + hp_off);
+        int* pw = pm + 5 * B + 2;
+        d_pcm = nullptr; total_samples = 0;
+        for (long f0 = 0; f0 < F; f0 += ss->chunk_frames) {
+            const long f1 = std::min<long>(F, f0 + ss->chunk_frames);
+            const long w0 = std::max<long>(0, f0 - halo), w1 = std::min<long>(F, f1 + halo);
+            pw[0] = (int)w0; pw[1] = 0; pw[2] = (int)(w1 - w0);
+            HIPCK(hipMemcpyAsync(d_win, pw, 3 * 4, hipMemcpyHostToDevice, stream));
+            const int rc = decode(1, w1 - w0, (int)(w1 - w0));
+            if (rc != STS_OK) return rc;
+            const long ns = (f1 - f0) * hop;
+            HIPCK(hipMemcpyAsync(hp, bf.pcm + (f0 - w0) * hop, (size_t)ns * 2, hipMemcpyDeviceToHost, stream));
+            HIPCK(hipStreamSynchronize(stream));
+            total_samples += ns;
+            if (ss->cb(ss->user, hp, (int32_t)ns, (int32_t)(f0 * hop)) != 0) break;
+        }
+        HIPCK(hipGetLastError());
+    }
+    const long Ntot = Ftot * hop;
 
     prof.frames = Ftot; prof.samples = Ntot; prof.phonemes = Ttot;
     prof.flops_text_encoder = flops_[0]; prof.flops_duration = flops_[1]; prof.flops_flow = flops_[2]; prof.flops_decoder = flops_[3];

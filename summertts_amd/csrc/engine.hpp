@@ -39,13 +39,17 @@ struct ConvOpt {
     int pad_l = -1;            // override the left padding (FFN same_padding)
 };
 
+// streaming decode: PCM is handed to `cb` chunk by chunk (cb returns non-zero to stop)
+struct StreamSpec { int chunk_frames; int (*cb)(void* user, const int16_t* pcm, int32_t n_samples, int32_t sample_offset); void* user; };
+int decoder_halo_frames(const Model& M);
+
 struct Tap { std::vector<float> data; int channels = 0; long length = 0; };
 
 class Engine {
 public:
     ~Engine();
     int init(const float* blob, int64_t bytes, int device);
-    int run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls);
+    int run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss = nullptr);
     const std::string& error() const { return err_; }
 
     Model model;

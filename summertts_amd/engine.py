@@ -87,6 +87,7 @@ EXPORTED_SYMBOLS = [
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_profiling",
     "sts_get_profile", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
+    "sts_infer_ids_stream", "sts_stream_halo_frames",
 ]
 
 
@@ -117,6 +118,33 @@ class Synthesizer:
 
     def infer_ids(self, ids: Sequence[int], sid: int = 0, length_scale: float = 1.0) -> np.ndarray:
         return self.infer_batch([ids], [sid], [length_scale])[0]
+
+    # -- streaming (sts_infer_ids_stream) -----------------------------------------------------
+    def infer_ids_stream(self, ids: Sequence[int], chunk_frames: int, sid: int = 0, length_scale: float = 1.0,
+                         on_chunk=None):
+        """Decodes chunk by chunk; ``on_chunk(pcm: np.int16[], sample_offset, t_seconds)`` is called per chunk
+        (return True to stop).  Returns (list of chunks, list of arrival times since the call started)."""
+        import time
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        chunks, times = [], []
+        t0 = time.perf_counter()
+
+        def _cb(user, pcm, n, off):
+            arr = np.ctypeslib.as_array(pcm, shape=(n,)).copy()
+            t = time.perf_counter() - t0
+            chunks.append(arr); times.append(t)
+            return 1 if (on_chunk and on_chunk(arr, off, t)) else 0
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int16), C.c_int32, C.c_int32)
+        cb = CB(_cb)
+        total = C.c_int32()
+        self.lib.sts_infer_ids_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, CB,
+                                                  C.c_void_p, C.POINTER(C.c_int32)]
+        _check(self.lib, self.lib.sts_infer_ids_stream(self.h, a.ctypes.data, a.size, sid, length_scale, chunk_frames, cb, None,
+                                                       C.byref(total)))
+        return chunks, times
+
+    def stream_halo_frames(self) -> int:
+        return int(self.lib.sts_stream_halo_frames(self.h))
 
     # -- batched -----------------------------------------------------------------------------
     def run_batch(self, ids: Sequence[Sequence[int]], sid: Optional[Sequence[int]] = None,

@@ -171,6 +171,17 @@ def test_full_size_properties(kind):
     assert np.array_equal(pinned[0], syn.infer_ids(ids[0]))
     assert np.array_equal(pinned[2], syn.infer_ids(ids[2]))
     syn.set_conv_mode(0)
+    # streaming decode (sts_infer_ids_stream): windows are smaller launches, so the automatic kernel choice may
+    # differ from the one-pass call (split-K sums K in another order): within 1 LSB; pinned kernel: bit-exact
+    chunks, _ = syn.infer_ids_stream(ids128, 64)
+    assert len(chunks) == -(-int(dur.sum()) // 64)
+    assert_pcm_close(np.concatenate(chunks), a, "streamed vs one pass (automatic kernel choice)")
+    syn.set_conv_mode(6)
+    one = syn.infer_ids(ids128)
+    for chunk in (48, 200):
+        chunks, _ = syn.infer_ids_stream(ids128, chunk)
+        assert np.array_equal(np.concatenate(chunks), one), chunk
+    syn.set_conv_mode(0)
     # generic VALU kernels and matrix-core kernels agree to fp32 noise
     syn.set_conv_mode(1)
     gen = syn.infer_ids(ids[0])
@@ -224,3 +235,30 @@ def test_malformed_blobs_are_rejected():
     syn = engine.Synthesizer(np.concatenate([blob, np.zeros(1000, np.float32)]))
     assert syn.info.blob_floats_consumed == blob.size
     syn.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["hifigan_sdp", "mbb_fix", "ms_sdp", "istft_fix", "ms_hifigan_sdp"])
+def test_streaming_equals_one_pass_bit_exact(kind):
+    """sts_infer_ids_stream: chunks decoded with receptive-field halos concatenate to exactly the
+    one-pass PCM, for every decoder family, for chunk sizes below / around / above the halo."""
+    cfg = sb.tiny_cfg(kind)
+    blob = sb.make_blob(cfg, 99)
+    syn = engine.Synthesizer(blob)
+    ids = sb.synthetic_ids(41, cfg.vocab, salt=5)
+    sid = 1 if cfg.is_ms else 0
+    full = syn.infer_ids(ids, sid=sid, length_scale=1.3)
+    halo = syn.stream_halo_frames()
+    assert 1 <= halo < 400
+    for chunk in (1, 7, halo, 3 * halo + 1, 100000):
+        chunks, times = syn.infer_ids_stream(ids, chunk, sid=sid, length_scale=1.3)
+        got = np.concatenate(chunks)
+        assert got.shape == full.shape, (kind, chunk, got.shape, full.shape)
+        assert np.array_equal(got, full), (kind, chunk, int(np.abs(got.astype(np.int32) - full).max()))
+        assert all(t1 >= t0 for t0, t1 in zip(times, times[1:]))
+    # early stop from the callback
+    chunks, _ = syn.infer_ids_stream(ids, 8, sid=sid, length_scale=1.3, on_chunk=lambda pcm, off, t: True)
+    assert len(chunks) == 1
+    # errors: bad chunk size
+    with pytest.raises(engine.StsError):
+        syn.infer_ids_stream(ids, 0)
