@@ -378,9 +378,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup 
 constexpr int RL_W1 = 128;            // intermediate columns per workgroup
 constexpr int RL_XW = RL_W1 + 64;     // staged input window: W1 + 2 * h1, h1 = d1 (k1 - 1) / 2 <= 32
 
-template <int MW>
-__global__ __launch_bounds__(256) void resblock_layer_kernel(ResLayerGroup G, int nx) {
-    constexpr int C = 32 * MW, NTHR = 256;
+template <int MW, int WM>
+__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 2 ? 4 : 1))) void resblock_layer_kernel(ResLayerGroup G, int nx) {
+    // WM row groups of 32 * MW channels x 4 column tiles of 32: 4 * WM waves
+    constexpr int C = 32 * MW * WM;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const t1 = smem;   // [C][RL_W1] (+ slack for masked columns); ALIASES the input staging buffers,
                               // which are dead once phase 1 has issued its last MFMA (barrier below)
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(256) void resblock_layer_kernel(ResLayerGroup G, in
     const int n0 = t.bx * NT;
     if (n0 >= len) return;
     const size_t base = (size_t)seg_start(G.seg, b);
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wn = (tid >> 6) & 3, wm = tid >> 8;
+    const int mbase = wm * MW * 32;
     const int l31 = lane & 31, half = lane >> 5;
 
     f32x16 acc[MW];
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256) void resblock_layer_kernel(ResLayerGroup G, in
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
     constexpr int nchunk = C / CK;
-    const unsigned a_voff = (unsigned)((half * C + l31) * 4);
+    const unsigned a_voff = (unsigned)((half * C + mbase + l31) * 4);
     float fa[3][CK / 2][MW], fb[2][CK / 2][1];
     int sj, sc, aj, ac;
 
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) void resblock_layer_kernel(ResLayerGroup G, in
             constexpr int i = decltype(ic)::value;
             static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[i][r];
                 if (a.b1) v += a.b1[row];
                 v = v < 0.f ? v * G.slope : v;
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(256) void resblock_layer_kernel(ResLayerGroup G, in
                 constexpr int i = decltype(ic)::value;
                 static_for<0, 16>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     float v = acc[i][r];
                     if (a.b2) v += a.b2[row];
                     a.y[(size_t)row * G.ld + opos] = v + a.x[(size_t)row * G.ld + opos];
@@ -807,7 +809,7 @@ static void launch_mfma_group(const ConvGroup& G, hipStream_t st) {
 }
 
 bool resblock_layer_eligible(const ResLayerGroup& G) {
-    if (G.n < 1 || G.n > kMaxGroup || (G.C != 32 && G.C != 64) || G.max_n <= 0 || G.B <= 0) return false;
+    if (G.n < 1 || G.n > kMaxGroup || (G.C != 32 && G.C != 64 && G.C != 128) || G.max_n <= 0 || G.B <= 0) return false;
     for (int i = 0; i < G.n; i++) {
         const ResLayerArgs& a = G.g[i];
         if (!(a.k1 & 1) || !(a.k2 & 1) || a.k1 < 1 || a.k2 < 1) return false;
@@ -832,8 +834,9 @@ void resblock_layer(const ResLayerGroup& Gin, hipStream_t st) {
     const size_t stage = (size_t)2 * CK * RL_XW, park = (size_t)G.C * RL_W1 + 64;
     const size_t lds = (stage > park ? stage : park) * sizeof(float);
     const dim3 grid(mapped_grid(nx, 1, G.B * G.n));
-    if (G.C == 32) hipLaunchKernelGGL((resblock_layer_kernel<1>), grid, dim3(256), lds, st, G, nx);
-    else hipLaunchKernelGGL((resblock_layer_kernel<2>), grid, dim3(256), lds, st, G, nx);
+    if (G.C == 32) hipLaunchKernelGGL((resblock_layer_kernel<1, 1>), grid, dim3(256), lds, st, G, nx);
+    else if (G.C == 64) hipLaunchKernelGGL((resblock_layer_kernel<2, 1>), grid, dim3(256), lds, st, G, nx);
+    else hipLaunchKernelGGL((resblock_layer_kernel<2, 2>), grid, dim3(512), lds, st, G, nx);
 }
 
 bool conv_group_eligible(const ConvGroup& G) {

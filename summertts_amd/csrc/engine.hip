@@ -497,7 +497,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 ResLayerGroup R;
                 memset(&R, 0, sizeof(R));
                 R.n = nk; R.C = up.Cout; R.ld = l2.ld; R.slope = 0.1f; R.seg = l2.seg; R.B = l2.nb; R.max_n = l2.max_len;
-                bool fuse = !no_fuse;
+                static const int fuse_maxc = getenv("STS_FUSE_MAXC") ? atoi(getenv("STS_FUSE_MAXC")) : 128;   // experiment knob
+                bool fuse = !no_fuse && R.C <= fuse_maxc;
                 for (int j = 0; j < nk && fuse; j++) {
                     const DResBlock& rb = M.rb[(size_t)i * nk + j];
                     const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
@@ -510,6 +511,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     R.g[j].x = cur[j]; R.g[j].y = nxt; R.g[j].w1 = c1.w; R.g[j].b1 = c1.bias; R.g[j].w2 = c2.w; R.g[j].b2 = c2.bias;
                     R.g[j].k1 = c1.k; R.g[j].dil1 = c1.dil; R.g[j].k2 = c2.k;
                 }
+                // the 128-channel variant runs 8-wave workgroups, two per CU: only worth it when the grid fills the chip twice
+                if (fuse && R.C > 64) fuse = (long)((l2.max_len + 117) / 118) * l2.nb * nk >= 512;
                 if (fuse && resblock_layer_eligible(R)) {
                     double fl = 0, f = 0;
                     for (int j = 0; j < nk; j++) {   // book FLOPs / algorithmic bytes exactly as for the two separate convs
