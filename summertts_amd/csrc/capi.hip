@@ -195,12 +195,21 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
             wp[((size_t)t * Cin_pad + ci) * Cout_pad + o] = w[((size_t)o * k + t) * Cin + ci];
     }
     if (bias) memcpy(bp.data(), bias, sizeof(float) * Cout);
-    float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr; int* dseg = nullptr;
+    // mode 12: the Winograd-domain kernel (weights transformed here the way load_model does it)
+    std::vector<float> wu;
+    int wn3 = 0, wn2 = 0;
+    if (mode == 12 && !depthwise && !tr) {
+        wino_split(k, &wn3, &wn2);
+        wu.resize((size_t)(wn3 + wn2) * 4 * Cin_pad * Cout_pad);
+        wino_pack(w, (long)k * Cin, Cin, 1, Cout, k, Cin, Cin_pad, Cout_pad, wu.data());
+    }
+    float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dwu = nullptr; int* dseg = nullptr;
     int seg[2] = {0, 1};
     bool ok = hipMalloc((void**)&dx, (size_t)Cin * L * 4) == hipSuccess && hipMalloc((void**)&dw, (wn + 1024) * 4) == hipSuccess &&
               hipMalloc((void**)&db, (size_t)Cout_pad * 4) == hipSuccess && hipMalloc((void**)&dy, (size_t)Cout * Lout * 4) == hipSuccess &&
               hipMalloc((void**)&dseg, 8) == hipSuccess;
     int rc = STS_OK;
+    if (ok && !wu.empty()) ok = hipMalloc((void**)&dwu, (wu.size() + 1024) * 4) == hipSuccess;
     if (!ok) rc = set_err(STS_EDEVICE, "hipMalloc failed");
     if (rc == STS_OK) {
         (void)hipMemcpy(dx, x, (size_t)Cin * L * 4, hipMemcpyHostToDevice);
@@ -218,11 +227,14 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         a.in_act = in_act; a.in_slope = in_slope; a.epi = EPI_STORE;
         // segment lengths in base units: in = L, out = Lout -> two views over the same {off=0,len=1} table
         a.in_seg = SegView{dseg, dseg + 1, L, 0}; a.out_seg = SegView{dseg, dseg + 1, Lout, 0}; a.B = 1;
+        if (dwu) { (void)hipMemcpy(dwu, wu.data(), wu.size() * 4, hipMemcpyHostToDevice); a.wu = dwu; a.wino_n3 = wn3; a.wino_n2 = wn2; }
         auto launch = [&]() {
-            if (mode != 1 && conv_mfma_eligible(a)) conv_mfma(a, nullptr, mode >= 2 ? mode - 2 : -1);
+            if (mode == 12) conv_wino(a, nullptr);
+            else if (mode != 1 && conv_mfma_eligible(a)) conv_mfma(a, nullptr, mode >= 2 ? mode - 2 : -1);
             else conv_generic(a, nullptr);
         };
-        if (mode >= 2 && !conv_mfma_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the matrix-core kernel");
+        if (mode == 12 && !conv_wino_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the Winograd kernel");
+        else if (mode >= 2 && mode != 12 && !conv_mfma_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the matrix-core kernel");
         else launch();
         if (rc == STS_OK && iters > 0 && ms_out) {   // steady-state timing of the same launch (HIP events, null stream)
             hipEvent_t e0, e1;
@@ -244,7 +256,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
             *y_out = y; *Lout_out = Lout;
         }
     }
-    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dseg);
+    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dseg); if (dwu) (void)hipFree(dwu);
     return rc;
 }
 

@@ -364,6 +364,210 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Winograd-domain conv: segmented F(2,3) on the matrix cores (fewer MFMAs for the same fp32 result)
+//
+// STATUS: validated groundwork, NOT on the product path.  Reachable through sts_debug_conv1d(mode 12)
+// (tests/test_parity_gpu.py, tools/conv_bench.py).  Measured on MI355X: as a single conv it
+// beats the direct kernel by 11-21 % on the 128/64/32-channel decoder shapes at batch 1 and reaches 122 vs
+// 110 TF/s (effective) at scale, but as a grouped launch it only ties the fused direct ResBlock-layer kernel
+// (and loses 7 % to it at batch 32), so the engine does not use it; a FUSED Winograd layer kernel is the
+// open follow-up.
+//
+// A dilated k-tap conv computes the output pair (y[n], y[n+d]) from x[n + j d], j = 0..k.  Cutting the taps
+// into 3-tap (and 2-tap) segments and applying the minimal-filtering identity F(2,3) to each segment,
+//     M0 += U0 (X0 - X2)   M1 += U1 (X1 + X2)   M2 += U2 (X2 - X1)   M3 += U3 (X1 - X3)
+//     y[n] = M0 + M1 + M2                      y[n+d] = M1 - M2 - M3
+// with X_m = x[n + (j0 + m) d] and U = G g precomputed per segment at load time (wino_pack), needs 4 (3) matrix
+// products per segment and output pair where the direct form needs 6 (4): k = 3 / 7 / 11 -> 4 / 10 / 15
+// MFMA sets instead of 6 / 14 / 22.  Only the well-conditioned points {0, 1, -1, inf} are used, so the fp32
+// error is ~1.2x the direct kernel's (checked against fp64 in tests); sums over segments and input channels
+// happen in the Winograd domain (the output transform is linear), i.e. four accumulators per output tile.
+//
+// Geometry: a wave owns 32 rows x 30 output PAIRS = 60 consecutive positions (30 = lcm of the dilations 1,
+// 2, 3, 5, 6, 10, 15; lanes 30/31 of the 32-wide MFMA tile idle), lane l = d q + r holds the pair
+// (2 d q + r, 2 d q + r + d).  The staged input row is stored de-interleaved -- position p = 2 d q + r + e d
+// lives at LDS index e H + d q + r -- so the fragment of X_j is ONE contiguous LDS read at
+// (j & 1) H + 30 wave + l + d (j >> 1), conflict-free.  K loop steps = (16-channel chunk, 8-channel half,
+// segment): 16 (12) MFMAs per step, A fragments through a 3-deep register ring, X values 2-deep.
+// ------------------------------------------------------------------------------------------------
+constexpr int WINO_NT = 240;          // output positions per workgroup (4 waves x 60)
+constexpr int WINO_H = 160;           // half-row length of the de-interleaved staged row
+constexpr int WINO_LD = 2 * WINO_H;
+
+template <int DUMMY>
+__device__ __forceinline__ void conv_wino_body(const ConvArgs& a, const int bx, const int by, const int b) {
+    constexpr int NTHR = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int in_len = seg_len(a.in_seg, b);
+    const int out_len = seg_len(a.out_seg, b);
+    const int n0 = bx * WINO_NT;
+    if (n0 >= out_len) return;
+    const int m0 = by * 32;
+    const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int d = a.tap_step, k = a.ntap;
+    const int n3 = a.wino_n3, nseg = a.wino_n3 + a.wino_n2;
+    const int Wneed = WINO_NT + (k - 1) * d;          // staged positions [w0, w0 + Wneed)
+    const int w0 = n0 + a.tap_off;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    const int nchunk = a.Cin_pad / CK;
+    const int nsteps = nchunk * 2 * nseg;
+
+    // A fragments: U[seg][xi][cin][cout]; one fragment (4 channel pairs of one xi) per sub-step
+    const rsrc_t wrs = make_rsrc(a.wu, (unsigned)((size_t)nseg * 4 * a.Cin_pad * a.Cout_pad * 4));
+    const unsigned a_voff = (unsigned)(((size_t)half * a.Cout_pad + m0 + l31) * 4);
+    const unsigned xi_stride = (unsigned)a.Cin_pad * (unsigned)a.Cout_pad * 4u;
+    auto load_a = [&](int c, int h, int sg, int xi, float (&dst)[4]) {
+        const unsigned sbase = ((unsigned)sg * 4u + (unsigned)xi) * xi_stride + (unsigned)((c * CK + h * 8) * a.Cout_pad) * 4u;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            dst[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                wrs, (int)a_voff, (int)(sbase + (unsigned)(2 * p) * (unsigned)a.Cout_pad * 4u), 0));
+    };
+    // X values of segment sg: X_m = staged row at tap j0 + m (one contiguous LDS read per (m, channel pair))
+    float X[4][4];
+    auto load_xv = [&](int bufi, int h, int sg) {
+        const int j0 = sg < n3 ? 3 * sg : 3 * n3 + 2 * (sg - n3);
+        const float* sb = smem + bufi * (CK * WINO_LD) + (h * 8 + half) * WINO_LD + 30 * wn + l31;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int j = j0 + m;
+            const float* sm = sb + (j & 1) * WINO_H + d * (j >> 1);
+#pragma unroll
+            for (int p = 0; p < 4; p++) X[m][p] = sm[2 * p * WINO_LD];
+        }
+    };
+
+    // staging: thread t owns window positions t and t + 256; a chunk is staged in two 8-row halves so that
+    // only 16 registers hold in-flight input (the accumulators already take 64)
+    unsigned xoff[2]; int lidx[2]; bool act1;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int p = tid + i * NTHR;
+        const int pos = w0 + p;
+        const bool act = p < Wneed;
+        if (i == 1) act1 = act;
+        xoff[i] = (act && pos >= 0 && pos < in_len) ? (unsigned)pos * 4u : kOOB;
+        const int q = p / (2 * d), rem = p - q * 2 * d, e = rem >= d ? 1 : 0;
+        lidx[i] = e * WINO_H + d * q + (rem - e * d);
+    }
+    float xr[8][2];
+    auto load_x = [&](int c, int hh) {          // rows hh*8 .. hh*8+7 of chunk c
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            if (i == 0 || act1) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int ci = c * CK + hh * 8 + r;
+                    xr[r][i] = buf_load(make_rsrc(a.x + (size_t)ci * a.x_ld + in_base, ci < a.Cin ? (unsigned)in_len * 4u : 0u), xoff[i]);
+                }
+            }
+    };
+    auto store_x = [&](int bufi, int hh) {
+        float* sb = smem + bufi * (CK * WINO_LD) + hh * 8 * WINO_LD;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            if (i == 0 || act1) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    float v = xr[r][i];
+                    if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
+                    sb[r * WINO_LD + lidx[i]] = v;
+                }
+            }
+    };
+
+    // ---- K loop: runtime loop over (chunk, half, segment) steps, four static sub-steps (xi) each.  The A ring
+    // slot IS xi; a fragment is requested three sub-steps before its MFMAs.  X is single-buffered: the next
+    // segment's values are read from LDS as soon as V3 has consumed the current ones, under xi = 3's MFMAs.
+    float fa[4][4];
+    int sc = 0, sh = 0, ss = 0;
+    load_x(0, 0); store_x(0, 0);
+    load_x(0, 1); store_x(0, 1);
+    load_a(0, 0, 0, 0, fa[0]);
+    load_a(0, 0, 0, 1, fa[1]);
+    load_a(0, 0, 0, 2, fa[2]);
+    __syncthreads();
+    load_xv(0, 0, 0);
+    if (nchunk > 1) load_x(1, 0);
+    for (int s = 0; s < nsteps; s++) {
+        int ns = ss + 1, nh = sh, nc = sc;
+        if (ns == nseg) { ns = 0; nh = sh + 1; if (nh == 2) { nh = 0; nc = sc + 1; } }
+        const bool more = s + 1 < nsteps;
+        const bool three = ss < n3;
+        float v[4];
+        // xi = 0
+        if (three) load_a(sc, sh, ss, 3, fa[3]);
+#pragma unroll
+        for (int p = 0; p < 4; p++) v[p] = X[0][p] - X[2][p];
+#pragma unroll
+        for (int p = 0; p < 4; p++) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][p], v[p], acc[0], 0, 0, 0);
+        // xi = 1
+        if (more) load_a(nc, nh, ns, 0, fa[0]);
+#pragma unroll
+        for (int p = 0; p < 4; p++) v[p] = X[1][p] + X[2][p];
+#pragma unroll
+        for (int p = 0; p < 4; p++) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][p], v[p], acc[1], 0, 0, 0);
+        // xi = 2
+        if (more) load_a(nc, nh, ns, 1, fa[1]);
+#pragma unroll
+        for (int p = 0; p < 4; p++) v[p] = X[2][p] - X[1][p];
+#pragma unroll
+        for (int p = 0; p < 4; p++) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2][p], v[p], acc[2], 0, 0, 0);
+        // xi = 3
+        if (more) load_a(nc, nh, ns, 2, fa[2]);
+#pragma unroll
+        for (int p = 0; p < 4; p++) v[p] = X[1][p] - X[3][p];
+        if (more) {
+            if (nc != sc) {                       // chunk boundary: publish the second half of chunk nc
+                store_x(nc & 1, 1);
+                __syncthreads();
+                if (nc + 1 < nchunk) load_x(nc + 1, 0);
+            } else if (nh != sh) {                // middle of the chunk: first half of chunk sc + 1 goes out
+                if (sc + 1 < nchunk) { store_x((sc + 1) & 1, 0); load_x(sc + 1, 1); }
+            }
+            load_xv(nc & 1, nh, ns);
+        }
+        if (three) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3][p], v[p], acc[3], 0, 0, 0);
+        }
+        ss = ns; sh = nh; sc = nc;
+    }
+
+    // ---- output transform + epilogue
+    if (l31 >= 30) return;
+    const int q = l31 / d, rr = l31 - q * d;
+    const int na = n0 + 60 * wn + 2 * d * q + rr, nb = na + d;
+    const bool va = na < out_len, vb = nb < out_len;
+    static_for<0, 16>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < a.Cout) {
+            float ya = acc[0][r] + acc[1][r] + acc[2][r];
+            float yb = acc[1][r] - acc[2][r] - acc[3][r];
+            float bv = a.bias ? a.bias[row] : 0.f;
+            if (a.ubias) bv += a.ubias[(size_t)row * a.ubias_ld + b];
+            if (va) epi_scalar(a, row, out_base + (size_t)na, ya + bv);
+            if (vb) epi_scalar(a, row, out_base + (size_t)nb, yb + bv);
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void conv_wino_kernel(ConvArgs a, int nx, int ny) {
+    const TileId t = map_tile(nx, ny, a.B);
+    if (!t.valid) return;
+    conv_wino_body<0>(a, t.bx, t.by, t.bz);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused ResBlock layer for the narrow decoder stages (C = 32 * MW <= 64)
 //   y = x + conv2_{k2,d=1}( lrelu( conv1_{k1,d1}( lrelu(x) ) ) )        (ResBlock1.cpp:55-69, one dilation)
 // Timing experiments on MI355X (tools/exp_build.sh) showed that at these widths a third of a conv's
@@ -837,6 +1041,40 @@ void resblock_layer(const ResLayerGroup& Gin, hipStream_t st) {
     if (G.C == 32) hipLaunchKernelGGL((resblock_layer_kernel<1, 1>), grid, dim3(256), lds, st, G, nx);
     else if (G.C == 64) hipLaunchKernelGGL((resblock_layer_kernel<2, 1>), grid, dim3(256), lds, st, G, nx);
     else hipLaunchKernelGGL((resblock_layer_kernel<2, 2>), grid, dim3(512), lds, st, G, nx);
+}
+
+bool conv_wino_eligible(const ConvArgs& a) {
+    if (!a.wu || a.transposed || a.depthwise || a.in_reflect || a.out_stride != 1 || a.out_off != 0) return false;
+    const int d = a.tap_step;
+    if (d <= 0 || d > 6 || 30 % d != 0 || a.ntap < 2) return false;
+    if (a.Cin_pad % CK != 0 || a.Cout_pad % 32 != 0 || a.Cin < 32) return false;
+    if ((a.ntap - 1) * d > MAX_HALO || 121 + d * ((a.ntap + 1) / 2) >= WINO_H) return false;
+    if (a.epi == EPI_GATE || a.epi == EPI_TANH_PCM) return false;
+    int n3, n2; wino_split(a.ntap, &n3, &n2);
+    return n3 == a.wino_n3 && n2 == a.wino_n2 && n3 >= 0;
+}
+static size_t wino_lds() { return (size_t)2 * CK * WINO_LD * sizeof(float); }
+void conv_wino(const ConvArgs& a, hipStream_t st) {
+    if (a.max_n <= 0 || a.B <= 0) return;
+    const int nx = (a.max_n + WINO_NT - 1) / WINO_NT, ny = a.Cout_pad / 32;
+    hipLaunchKernelGGL(conv_wino_kernel, dim3(mapped_grid(nx, ny, a.B)), dim3(256), wino_lds(), st, a, nx, ny);
+}
+// U = G g per segment, in double, rounded once
+void wino_pack(const float* w, long s_out, long s_tap, long s_in, int Cout, int k, int Cin, int Cin_pad, int Cout_pad, float* dst) {
+    int n3, n2; wino_split(k, &n3, &n2);
+    const int nseg = n3 + n2;
+    const size_t slab = (size_t)Cin_pad * Cout_pad;
+    for (size_t i = 0; i < (size_t)nseg * 4 * slab; i++) dst[i] = 0.f;
+    for (int sg = 0; sg < nseg; sg++) {
+        const int j0 = sg < n3 ? 3 * sg : 3 * n3 + 2 * (sg - n3), len = sg < n3 ? 3 : 2;
+        for (int o = 0; o < Cout; o++)
+            for (int ci = 0; ci < Cin; ci++) {
+                double g[3] = {0, 0, 0};
+                for (int t = 0; t < len; t++) g[t] = (double)w[(size_t)o * s_out + (size_t)(j0 + t) * s_tap + (size_t)ci * s_in];
+                const double u[4] = {g[0], 0.5 * (g[0] + g[1] + g[2]), 0.5 * (g[0] - g[1] + g[2]), g[2]};
+                for (int xi = 0; xi < 4; xi++) dst[((size_t)sg * 4 + xi) * slab + (size_t)ci * Cout_pad + o] = (float)u[xi];
+            }
+    }
 }
 
 bool conv_group_eligible(const ConvGroup& G) {

@@ -49,7 +49,18 @@ struct ConvArgs {
     int gate_perm;                  // EPI_GATE rows are packed in (tanh32, sigmoid32) tile pairs
     SegView in_seg, out_seg;
     int B, max_n;                   // batch size, max n_count over the batch (grid sizing)
+    // optional Winograd form of the same weights (conv_wino_*): [seg][4][Cin_pad][Cout_pad], see wino_pack()
+    const float* wu; int wino_n3, wino_n2;
 };
+
+// Segmented Winograd F(2,3): a k-tap filter is cut into n3 three-tap segments followed by n2 two-tap segments
+// (k = 3 n3 + 2 n2, n2 in {0,1,2}); every segment contributes 4 (3-tap) or 3 (2-tap) products per pair of
+// outputs instead of 6 / 4, and all segments accumulate into the same four Winograd-domain sums.
+inline void wino_split(int k, int* n3, int* n2) { *n2 = (k % 3 == 0) ? 0 : (k % 3 == 2 ? 1 : 2); *n3 = (k - 2 * *n2) / 3; }
+// w: [Cout][k][Cin] source order (or any accessor order given by the strides), dst: [seg][4][Cin_pad][Cout_pad]
+void wino_pack(const float* w, long s_out, long s_tap, long s_in, int Cout, int k, int Cin, int Cin_pad, int Cout_pad, float* dst);
+bool conv_wino_eligible(const ConvArgs& a);
+void conv_wino(const ConvArgs& a, hipStream_t st);
 
 struct LnArgs {
     const float* a; long a_ld;      // v = a (+ b)

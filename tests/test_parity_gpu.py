@@ -16,6 +16,8 @@ CONV_CASES = [  # Cin, Cout, k, pad, dil, L, stride_transposed, depthwise
     (64, 32, 8, 2, 1, 100, 4, False), (128, 64, 16, 4, 1, 65, 8, False), (24, 12, 7, 2, 1, 33, 3, False),
     (16, 16, 3, 9, 9, 120, 0, True), (64, 72, 7, 3, 1, 500, 0, False), (256, 256, 3, 1, 1, 1000, 0, False),
     (32, 1, 7, 3, 1, 1000, 0, False), (4, 1, 63, 31, 1, 400, 0, False), (192, 384, 5, 2, 1, 31, 0, False),
+    (128, 128, 7, 9, 3, 1500, 0, False), (128, 128, 11, 25, 5, 777, 0, False), (64, 64, 9, 8, 2, 241, 0, False),
+    (256, 256, 13, 6, 1, 480, 0, False), (32, 32, 3, 6, 6, 239, 0, False),
 ]
 
 
@@ -46,6 +48,13 @@ def test_conv_kernels_against_torch_fp32(case):
     if mfma_ok:   # every LDS-staged matrix-core tile shape walks K in the same order: bit-identical results
         for mode in (3, 4, 5, 6, 7):
             assert np.array_equal(outs[mode], outs[2]), (case, mode)
+    # Winograd-domain kernel (segmented F(2,3)): same tolerance as the direct kernels
+    if mfma_ok and not st and k >= 2 and dil in (1, 2, 3, 5, 6) and (k - 1) * dil <= 64:
+        y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=12)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() <= 2e-5, (case, "winograd", np.abs(y - ref).max())
+        y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=12)
+        assert np.abs(y - engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=0)).max() <= 2e-5
     # fused input leaky-relu
     y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=0)
     y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=0)

@@ -20,7 +20,7 @@ SHAPES = [  # name, Cin, Cout, k, dil, L, stride_t
     ("mbb_s2_k3", 128, 128, 3, 1, 16 * F, 0), ("mbb_s2_k11d5", 128, 128, 11, 5, 16 * F, 0),
     ("s4_k3", 32, 32, 3, 1, 256 * F, 0), ("s4_k7d3", 32, 32, 7, 3, 256 * F, 0), ("s4_k11d5", 32, 32, 11, 5, 256 * F, 0),
 ]
-MODES = {0: "auto", 2: "128x128", 3: "64x256", 4: "32x512", 5: "64x128", 6: "32x128", 7: "32x256", 8: "splitk32", 9: "splitk64"}
+MODES = {12: "wino", 0: "auto", 2: "128x128", 3: "64x256", 4: "32x512", 5: "64x128", 6: "32x128", 7: "32x256", 8: "splitk32", 9: "splitk64"}
 
 def main():
     only = sys.argv[1:] if len(sys.argv) > 1 else None
