@@ -152,33 +152,24 @@ def main():
     elapsed = time.perf_counter() - t0
     last = syn.profile()
 
-    # ---- extra figure: N engines on one GPU, one host thread each (serving-style pipelining of requests)
+    # ---- extra figure (not the headline): the native request pool (sts_pool: N engines, one worker thread each,
+    # one FIFO).  "pipelined" = batch-1 requests only overlapped across engines (max_batch 1); "burst" = the same
+    # requests submitted at once with dynamic packed batching (max_batch 8).
     pipelined = None
     if dist is None and args.pipeline_engines >= 2:
-        import threading
-        engines = [syn] + [eng.Synthesizer(blob, device=0) for _ in range(args.pipeline_engines - 1)]
-        for e_ in engines:
-            e_.set_conv_mode(args.conv_mode)
-            e_.set_profiling(False)
-            e_.run_batch(ids, sid, ls)
-        per_thread = max(4, args.steps // 2)
-        done = [0] * len(engines)
-
-        def worker(k):
-            for _ in range(per_thread):
-                n_out = engines[k].run_batch(ids, sid, ls)
-                engines[k].pcm_host()
-                done[k] += int(n_out.sum())
-        ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(engines))]
-        tp0 = time.perf_counter()
-        for t_ in ths:
-            t_.start()
-        for t_ in ths:
-            t_.join()
-        tp = time.perf_counter() - tp0
-        pipelined = {"engines": len(engines), "value": sum(done) / tp, "unit": "samples/s", "x_realtime_16khz": sum(done) / tp / 16000.0,
-                     "ms_per_utterance": 1e3 * tp / (per_thread * len(engines) * max(1, len(ids)))}
-        syn.set_profiling(True)
+        nreq = max(8, args.steps)
+        pipelined = {"engines": args.pipeline_engines, "requests": nreq}
+        for label, mb in (("pipelined_batch1", 1), ("burst_max_batch8", 8)):
+            pool = eng.Pool(blob, device=0, n_engines=args.pipeline_engines, max_batch=mb)
+            for t_ in [pool.submit(ids[0], sid[0], ls[0]) for _ in range(2 * args.pipeline_engines)]:
+                pool.wait(t_)                                    # warm-up: every engine has run once
+            tp0 = time.perf_counter()
+            tk = [pool.submit(ids[u % len(ids)], sid[u % len(ids)], ls[u % len(ids)]) for u in range(nreq)]
+            done = sum(int(pool.wait(t_).size) for t_ in tk)
+            tp = time.perf_counter() - tp0
+            pipelined[label] = {"value": done / tp, "unit": "samples/s", "x_realtime_16khz": done / tp / 16000.0,
+                                "ms_per_request": 1e3 * tp / nreq}
+            pool.close()
 
     total_samples = samples
     if dist is not None:
@@ -243,7 +234,7 @@ def main():
             },
         }
         if pipelined is not None:
-            out["pipelined_engines"] = pipelined
+            out["request_pool"] = pipelined
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(blob, cfg, cfg.vocab, args.cpu_sample_phonemes)

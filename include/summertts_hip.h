@@ -133,6 +133,19 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
 void sts_free(void* p);
 const char* sts_last_error(void);
 
+/* ---- request pool (no reference counterpart: SynthesizerTrn::infer is one blocking call per
+ * utterance, SynthesizerTrn.cpp:323).  n_engines engines on one GPU, one worker thread each, one FIFO; a free
+ * worker folds up to max_batch queued requests into ONE packed variable-length batch.  submit() returns a
+ * ticket (> 0) or a negative STS_E* code; wait() blocks until that request is done and hands back a
+ * malloc()'d PCM buffer (release with sts_free).  Thread-safe: any thread may submit / wait. */
+typedef struct sts_pool sts_pool;
+int sts_pool_create(const float* blob, int64_t blob_bytes, int device, int n_engines, int max_batch, sts_pool** out);
+void sts_pool_destroy(sts_pool* p);
+int64_t sts_pool_submit(sts_pool* p, const int32_t* ids, int32_t n, int32_t sid, float length_scale);
+int sts_pool_wait(sts_pool* p, int64_t ticket, int16_t** pcm_out, int32_t* n_out);
+int sts_pool_stats(sts_pool* p, int64_t* batches, int64_t* requests);
+const char* sts_pool_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,7 @@ EXPORTED_SYMBOLS = [
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_profiling",
     "sts_get_profile", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
     "sts_infer_ids_stream", "sts_stream_halo_frames",
+    "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
 ]
 
 
@@ -245,3 +246,55 @@ def debug_conv1d(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], pad: 
     out = np.ctypeslib.as_array(y, shape=(cout, lout.value)).copy()
     lib.sts_free(y)
     return (out, float(ms.value)) if iters > 0 else out
+
+
+class Pool:
+    """``sts_pool``: N engines on one GPU behind one request queue (dynamic packed batching)."""
+
+    def __init__(self, blob: np.ndarray, device: int = 0, n_engines: int = 2, max_batch: int = 8):
+        self.lib = load_library()
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self.h = C.c_void_p()
+        self.lib.sts_pool_last_error.restype = C.c_char_p
+        self.lib.sts_pool_submit.restype = C.c_int64
+        self.lib.sts_pool_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float]
+        self.lib.sts_pool_wait.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(C.c_int32)]
+        self.lib.sts_pool_create.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        self.lib.sts_pool_destroy.argtypes = [C.c_void_p]
+        self.lib.sts_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        rc = self.lib.sts_pool_create(blob.ctypes.data, blob.nbytes, device, n_engines, max_batch, C.byref(self.h))
+        if rc != 0:
+            raise StsError(f"sts_pool_create: {rc}: {self.lib.sts_pool_last_error().decode()}")
+
+    def submit(self, ids: Sequence[int], sid: int = 0, length_scale: float = 1.0) -> int:
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        t = int(self.lib.sts_pool_submit(self.h, a.ctypes.data, a.size, sid, length_scale))
+        if t <= 0:
+            raise StsError(f"sts_pool_submit: {t}: {self.lib.sts_pool_last_error().decode()}")
+        return t
+
+    def wait(self, ticket: int) -> np.ndarray:
+        p = C.POINTER(C.c_int16)()
+        n = C.c_int32()
+        rc = self.lib.sts_pool_wait(self.h, ticket, C.byref(p), C.byref(n))
+        if rc != 0:
+            raise StsError(f"sts_pool_wait: {rc}: {self.lib.sts_pool_last_error().decode()}")
+        out = np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int16)
+        self.lib.sts_free(p)
+        return out
+
+    def stats(self):
+        b, r = C.c_int64(), C.c_int64()
+        self.lib.sts_pool_stats(self.h, C.byref(b), C.byref(r))
+        return int(b.value), int(r.value)
+
+    def close(self):
+        if self.h:
+            self.lib.sts_pool_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

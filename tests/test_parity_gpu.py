@@ -271,3 +271,43 @@ def test_streaming_equals_one_pass_bit_exact(kind):
     # errors: bad chunk size
     with pytest.raises(engine.StsError):
         syn.infer_ids_stream(ids, 0)
+
+
+def test_request_pool_matches_direct_calls():
+    """sts_pool: requests submitted from several threads come back with the PCM a direct
+    sts_infer_ids call produces (within 1 LSB: a request may run alone or folded into a packed batch), tickets
+    complete in any wait order, batching really happens, and a bad request only fails itself."""
+    import threading
+    cfg = sb.tiny_cfg("ms_hifigan_sdp")
+    blob = sb.make_blob(cfg, 21)
+    syn = engine.Synthesizer(blob)
+    reqs = [(sb.synthetic_ids(9 + 5 * (i % 7), cfg.vocab, salt=i), i % cfg.spk_num, 1.0 + 0.1 * (i % 3)) for i in range(24)]
+    want = [syn.infer_ids(ids, sid=s, length_scale=ls) for ids, s, ls in reqs]
+    pool = engine.Pool(blob, n_engines=2, max_batch=6)
+    tickets = [None] * len(reqs)
+
+    def producer(lo, hi):
+        for i in range(lo, hi):
+            tickets[i] = pool.submit(*reqs[i])
+    ths = [threading.Thread(target=producer, args=(k * 8, k * 8 + 8)) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert len(set(tickets)) == len(reqs) and all(t > 0 for t in tickets)
+    for i in reversed(range(len(reqs))):          # wait in reverse order
+        assert_pcm_close(pool.wait(tickets[i]), want[i], f"pool request {i}")
+    batches, done = pool.stats()
+    assert done == len(reqs) and batches < len(reqs), (batches, done)     # some requests shared a batch
+    # a bad id fails alone; its neighbours still complete
+    good1 = pool.submit(*reqs[0])
+    bad = pool.submit([0, cfg.vocab + 5, 1], 0, 1.0)
+    good2 = pool.submit(*reqs[1])
+    assert_pcm_close(pool.wait(good1), want[0], "neighbour of a bad request")
+    with pytest.raises(engine.StsError):
+        pool.wait(bad)
+    assert_pcm_close(pool.wait(good2), want[1], "neighbour of a bad request")
+    with pytest.raises(engine.StsError):
+        pool.wait(12345678)                      # unknown ticket
+    pool.close()
+    syn.close()
