@@ -187,6 +187,10 @@ def test_full_size_properties(kind):
     assert_pcm_close(np.concatenate(chunks), a, "streamed vs one pass (automatic kernel choice)")
     syn.set_conv_mode(6)
     one = syn.infer_ids(ids128)
+    # the split-K kernel family (pinned) is an independent implementation of every conv: it must agree with the
+    # grouped / fused-layer kernels the automatic path used for `a` (the 128-channel fused kernel only engages
+    # at this size)
+    assert_pcm_close(one, a, "split-K kernels vs grouped/fused kernels at full size")
     for chunk in (48, 200):
         chunks, _ = syn.infer_ids_stream(ids128, chunk)
         assert np.array_equal(np.concatenate(chunks), one), chunk
