@@ -315,3 +315,23 @@ def test_request_pool_matches_direct_calls():
         pool.wait(12345678)                      # unknown ticket
     pool.close()
     syn.close()
+
+
+def test_realistic_size_against_the_real_reference():
+    """The kernels that only engage at realistic launch sizes (grouped ResBlock launches, the fused layer kernels
+    incl. the 128-channel one, the LDS-staged upsamplers) against the reference's own Eigen path: full-size
+    HiFi-GAN model, 72 phonemes (~380 frames, ~97 k samples; ~10-20 s of CPU time on the GPU box's host cores)."""
+    if not pyref.have_ref():
+        pytest.skip("oracle/_ref (the compiled reference) did not travel; the plain-C restatement is too slow at this size")
+    cfg = sb.full_cfg("hifigan_sdp")
+    blob = sb.make_blob(cfg, 1234)
+    ids = sb.synthetic_ids(72, cfg.vocab, salt=3)
+    o = pyref.RefModel(blob).infer_ids(ids, 0, 1.0)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    syn.run_batch([ids])
+    assert (syn.durations(72) == o["durations"]).all()
+    assert int(o["durations"].sum()) >= 330          # large enough for the 128-channel fused kernel (>= 512 workgroups)
+    assert_wave_close(syn.tap("wave")[0], o["wave"], "realistic size vs reference")
+    assert_pcm_close(syn.pcm_host(), o["pcm"], "realistic size vs reference")
+    syn.close()
