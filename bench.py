@@ -115,13 +115,45 @@ def main():
     sid = [u % max(1, syn.get_speaker_num()) for u in mine]
     ls = [1.0] * len(ids)
 
+    # N > 1: the PCM gather of step k (count exchange + RCCL gather + download + unpack on rank 0) runs on a
+    # helper thread while the main thread already synthesises step k + 1; every gather is completed before the
+    # clock stops (drain()).  Collectives are issued by ONE thread per rank, in step order.
+    gq = None
+    if dist is not None:
+        import queue
+        import threading
+        gq = queue.Queue()
+        gathered = [0]
+
+        def gather_worker():
+            torch.cuda.set_device(local_rank)
+            while True:
+                item = gq.get()
+                if item is None:
+                    gq.task_done()
+                    return
+                local, counts = item
+                res = sharding.gather_variable(local, counts, dist, torch, rank, world, max_utts)
+                if res is not None:
+                    gathered[0] += sum(int(a_.size) for per_rank in res for a_ in per_rank)
+                gq.task_done()
+        gth = threading.Thread(target=gather_worker, daemon=True)
+        gth.start()
+
     def step():
         n_out = syn.run_batch(ids, sid, ls)
         if dist is None:
             pcm = syn.pcm_host()
             return int(n_out.sum()), pcm
-        pcm, counts = sharding.gather_pcm(syn, n_out, dist, torch, rank, world, max_utts)
-        return int(n_out.sum()), pcm
+        total = int(n_out.sum())
+        local = torch.empty(max(1, total), dtype=torch.int16, device="cuda")
+        syn.pcm_to_device_ptr(local.data_ptr(), local.numel())      # device-to-device; the engine is free again
+        gq.put((local[:total], [int(v) for v in n_out]))
+        return total, None
+
+    def drain():
+        if gq is not None:
+            gq.join()
 
     def sync():
         torch.cuda.synchronize()
@@ -131,6 +163,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     syn.set_profiling(True)
     sync()
     lat = []
@@ -148,6 +181,7 @@ def main():
         mfma_ms += p["ms_decoder_mfma"]; mfma_flops += p["flops_decoder_mfma"]; launches += p["decoder_mfma_launches"]
         dec_ms += p["ms_decoder"]; dec_flops += p["flops_decoder"]; dec_bytes += p["bytes_decoder_min"]
         stage_ms += np.array([p["ms_text_encoder"], p["ms_duration"], p["ms_flow"], p["ms_decoder"]])
+    drain()
     sync()
     elapsed = time.perf_counter() - t0
     last = syn.profile()

@@ -27,37 +27,58 @@ def shard_utterances(lengths: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
-def gather_variable(local, counts_local, dist, torch, rank: int, world: int, max_utts: int):
-    """Gathers one variable-length int16 tensor per rank to rank 0.
+class PendingGather:
+    """Handle of a gather whose payload is still in flight (see begin_gather / finish_gather)."""
+    __slots__ = ("work", "big", "buf", "cnts", "rank", "world")
+
+
+def begin_gather(local, counts_local, dist, torch, rank: int, world: int, max_utts: int) -> PendingGather:
+    """Starts the gather of one variable-length int16 tensor per rank to rank 0 and returns at once.
 
     local: 1-D int16 tensor (on the backend's device) holding this rank's utterances back to back;
-    counts_local: per-utterance sample counts (python ints).  Returns on rank 0 a list (per rank) of
-    lists (per utterance) of numpy int16 arrays; ``None`` elsewhere."""
+    counts_local: per-utterance sample counts (python ints).  The sample counts are exchanged first (one tiny
+    all_gather + one download: the payload buffers are sized from them); the PCM itself travels asynchronously
+    (``async_op``) so that the caller can start the next batch while RCCL moves it."""
     dev = local.device
-    cnt = torch.zeros(max_utts + 1, dtype=torch.int64, device=dev)
-    cnt[0] = len(counts_local)
-    if len(counts_local):
-        cnt[1:1 + len(counts_local)] = torch.as_tensor(list(counts_local), dtype=torch.int64, device=dev)
-    all_cnt = [torch.zeros_like(cnt) for _ in range(world)]
+    cnt_h = np.zeros(max_utts + 1, dtype=np.int64)
+    cnt_h[0] = len(counts_local)
+    cnt_h[1:1 + len(counts_local)] = list(counts_local)
+    cnt = torch.from_numpy(cnt_h).to(dev)
+    all_cnt = [torch.empty_like(cnt) for _ in range(world)]
     dist.all_gather(all_cnt, cnt)
-    totals = [int(c[1:1 + int(c[0])].sum().item()) for c in all_cnt]
+    cnts = torch.stack(all_cnt).cpu().numpy()
+    totals = [int(cnts[r, 1:1 + int(cnts[r, 0])].sum()) for r in range(world)]
     cap = max(1, max(totals))
-    buf = torch.zeros(cap, dtype=torch.int16, device=dev)
+    # int16 travels as raw bytes: every backend (RCCL, gloo) moves uint8.  The tail beyond this rank's samples
+    # is never read on the root, so the send buffer is not cleared.
+    buf = torch.empty(cap, dtype=torch.int16, device=dev)
     buf[:local.numel()] = local
-    # int16 travels as raw bytes: every backend (RCCL, gloo) moves uint8
-    bbuf = buf.view(torch.uint8)
-    gl = [torch.zeros(cap * 2, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-    dist.gather(bbuf, gl, dst=0)
-    if rank != 0:
+    h = PendingGather()
+    h.buf = buf; h.cnts = cnts; h.rank = rank; h.world = world
+    h.big = torch.empty((world, cap * 2), dtype=torch.uint8, device=dev) if rank == 0 else None
+    h.work = dist.gather(buf.view(torch.uint8), list(h.big.unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+    return h
+
+
+def finish_gather(h: PendingGather):
+    """Completes begin_gather: on rank 0 a list (per rank) of lists (per utterance) of numpy int16 arrays,
+    ``None`` elsewhere."""
+    h.work.wait()
+    if h.rank != 0:
         return None
+    host = h.big.cpu().numpy().view(np.int16)      # [world, cap]: one device-to-host copy
     out = []
-    for r in range(world):
-        host = gl[r].view(torch.int16).cpu().numpy()
-        k = int(all_cnt[r][0].item())
-        cs = [int(v) for v in all_cnt[r][1:1 + k].tolist()]
+    for r in range(h.world):
+        k = int(h.cnts[r, 0])
+        cs = [int(v) for v in h.cnts[r, 1:1 + k]]
         offs = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
-        out.append([host[offs[i]:offs[i + 1]].copy() for i in range(k)])
+        out.append([host[r, offs[i]:offs[i + 1]].copy() for i in range(k)])
     return out
+
+
+def gather_variable(local, counts_local, dist, torch, rank: int, world: int, max_utts: int):
+    """Blocking form: begin_gather + finish_gather."""
+    return finish_gather(begin_gather(local, counts_local, dist, torch, rank, world, max_utts))
 
 
 def gather_pcm(syn, n_out, dist, torch, rank: int, world: int, max_utts: int = 0):
@@ -68,3 +89,12 @@ def gather_pcm(syn, n_out, dist, torch, rank: int, world: int, max_utts: int = 0
     res = gather_variable(local[:total], [int(v) for v in n_out], dist, torch, rank, world,
                           max_utts or max(1, len(n_out)))
     return res, n_out
+
+
+def begin_gather_pcm(syn, n_out, dist, torch, rank: int, world: int, max_utts: int = 0) -> PendingGather:
+    """Asynchronous form of gather_pcm: the engine's PCM is copied out (device to device) and handed to RCCL;
+    the engine is free for the next batch as soon as this returns."""
+    total = int(np.asarray(n_out).sum())
+    local = torch.empty(max(1, total), dtype=torch.int16, device="cuda")
+    syn.pcm_to_device_ptr(local.data_ptr(), local.numel())
+    return begin_gather(local[:total], [int(v) for v in n_out], dist, torch, rank, world, max_utts or max(1, len(n_out)))

@@ -33,13 +33,21 @@ def _worker(rank, world, port, q):
     pcs = [np.full(lens[u] * 3, u + 1, np.int16) + np.arange(lens[u] * 3, dtype=np.int16) for u in mine]
     local = torch.from_numpy(np.concatenate(pcs)) if pcs else torch.zeros(0, dtype=torch.int16)
     res = sharding.gather_variable(local, [p.size for p in pcs], dist, torch, rank, world, max_utts)
+    # pipelined form used by bench.py: the gather of step k is still in flight while step k + 1 is issued
+    local2 = (local + 7).to(torch.int16)
+    h1 = sharding.begin_gather(local, [p.size for p in pcs], dist, torch, rank, world, max_utts)
+    h2 = sharding.begin_gather(local2, [p.size for p in pcs], dist, torch, rank, world, max_utts)
+    res1 = sharding.finish_gather(h1)
+    res2 = sharding.finish_gather(h2)
     if rank == 0:
         ok = True
         for r in range(world):
             for k, u in enumerate(shards[r]):
                 exp = np.full(lens[u] * 3, u + 1, np.int16) + np.arange(lens[u] * 3, dtype=np.int16)
-                ok = ok and np.array_equal(res[r][k], exp)
+                ok = ok and np.array_equal(res[r][k], exp) and np.array_equal(res1[r][k], exp) and np.array_equal(res2[r][k], exp + 7)
         q.put(ok)
+    else:
+        assert res is None and res1 is None and res2 is None
     dist.destroy_process_group()
 
 
