@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
 // the KS partial accumulators are summed through LDS once, followed by the same fused epilogues.
 // ------------------------------------------------------------------------------------------------
 template <int MW, int NW>
-__global__ __launch_bounds__(MW * NW <= 1 ? 1024 : (MW * NW <= 2 ? 512 : 256)) void conv_mfma_splitk_kernel(ConvArgs a, int mtiles) {
+__global__ __launch_bounds__(MW * NW <= 2 ? 1024 : 256) void conv_mfma_splitk_kernel(ConvArgs a, int mtiles) {
     constexpr int G = 4, E = MW * NW * 16;
     constexpr int D = MW * NW == 1 ? 6 : (MW * NW == 2 ? 4 : 3);   // register ring depth (groups in flight)
     extern __shared__ __attribute__((aligned(16))) float red[];   // [KS][E][64]
@@ -992,7 +992,10 @@ static void launch_splitk(const ConvArgs& a, int nphase, hipStream_t st) {
     const int nt = (a.max_n + 32 * NW - 1) / (32 * NW);
     const long steps = (long)a.ntap * (a.Cin_pad / 8);          // groups of 4 channel pairs
     constexpr int E = MW * NW * 16;
-    const int ks_cap = E <= 16 ? 16 : (E <= 32 ? 8 : 4);        // LDS for the partial tiles <= 64 KiB
+    // LDS for the partial tiles: <= 64 KiB normally; a grid that cannot even give every CU one workgroup may take
+    // 128 KiB (16 waves on a two-tile workgroup: half the dependent L2/HBM round trips per wave)
+    const bool sparse = (long)mt * nt * nphase * a.B <= 256;
+    const int ks_cap = E <= 16 ? 16 : (E <= 32 ? (sparse ? 16 : 8) : 4);
     // enough waves that each one issues >= ~6 groups (24 MFMA rounds), but do not drown the chip
     int ks = 1;
     while (ks < ks_cap && steps / (ks * 2) >= 6 && (long)mt * nt * nphase * a.B * ks * 2 <= 4096) ks *= 2;
