@@ -74,9 +74,16 @@ __global__ __launch_bounds__(1024) void layer_norm_kernel(LnArgs a) {
     const bool live = pos < len;
     const size_t p = (size_t)seg_start(a.seg, b) + (live ? pos : 0);
     constexpr int MAXV = 8;                 // values kept in registers between the two passes (C <= 256)
-    float vals[MAXV];
+    float vals[MAXV], gam[MAXV], bet[MAXV], rsd[MAXV];
     float s = 0.f, sq = 0.f;
     if (live) {
+        // affine parameters and the residual do not depend on the statistics: their loads are issued together
+        // with the input's, so the kernel has ONE memory round trip before the reduction instead of two
+#pragma unroll
+        for (int u = 0; u < MAXV; u++) {
+            const int c = cy + u * LN_G;
+            if (c < a.C) { gam[u] = a.gamma[c]; bet[u] = a.beta[c]; rsd[u] = a.res ? a.res[(size_t)c * a.res_ld + p] : 0.f; }
+        }
 #pragma unroll
         for (int u = 0; u < MAXV; u++) {
             const int c = cy + u * LN_G;
@@ -103,7 +110,12 @@ __global__ __launch_bounds__(1024) void layer_norm_kernel(LnArgs a) {
 #pragma unroll
     for (int u = 0; u < MAXV; u++) {
         const int c = cy + u * LN_G;
-        if (c < a.C) finish(c, vals[u]);
+        if (c < a.C) {
+            float o = ((vals[u] - mean) / den) * gam[u] + bet[u];
+            if (a.post_gelu) o = gelu_ref(o);
+            if (a.res) o = rsd[u] + o;
+            a.y[(size_t)c * a.y_ld + p] = o;
+        }
     }
     for (int c = cy + MAXV * LN_G; c < a.C; c += LN_G) finish(c, ln_input(a, c, p, pos, len));
 }
