@@ -366,12 +366,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup 
 // ------------------------------------------------------------------------------------------------
 // Winograd-domain conv: segmented F(2,3) on the matrix cores (fewer MFMAs for the same fp32 result)
 //
-// STATUS: validated groundwork, NOT on the product path.  Reachable through sts_debug_conv1d(mode 12)
-// (tests/test_parity_gpu.py, tools/conv_bench.py).  Measured on MI355X: as a single conv it
-// beats the direct kernel by 11-21 % on the 128/64/32-channel decoder shapes at batch 1 and reaches 122 vs
-// 110 TF/s (effective) at scale, but as a grouped launch it only ties the fused direct ResBlock-layer kernel
-// (and loses 7 % to it at batch 32), so the engine does not use it; a FUSED Winograd layer kernel is the
-// open follow-up.
+// This single-conv kernel is reachable through sts_debug_conv1d(mode 12) (tests, tools/conv_bench.py); the product
+// path uses the same arithmetic inside the fused layer kernel below (resblock_wino_kernel).  Measured on MI355X
+// (DESIGN.md 5): as a single conv it beats the direct kernel by 11-21 % on the 128/64/32-channel decoder shapes.
 //
 // A dilated k-tap conv computes the output pair (y[n], y[n+d]) from x[n + j d], j = 0..k.  Cutting the taps
 // into 3-tap (and 2-tap) segments and applying the minimal-filtering identity F(2,3) to each segment,
@@ -779,6 +776,255 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused ResBlock layer, both convs in the Winograd domain (resblock_layer_kernel x conv_wino_body)
+//   WM row groups of 32 channels x WN column groups of 30 output pairs (60 positions): 4 accumulators per wave.
+//   Phase 1 produces P = 60 WN intermediate positions (conv2's halo included) and parks them in LDS in the
+//   de-interleaved layout conv2 (dilation 1) reads: position p at (p & 1) H2 + (p >> 1); phase 2 runs conv2 out of
+//   that tile.  K loops: (16-channel chunk, 8-channel half, segment) steps of four static sub-steps, as in
+//   conv_wino_body.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WM * WN >= 8 ? 4 : 1)))
+void resblock_wino_kernel(ResLayerGroup G, int nx) {
+    constexpr int C = 32 * WM, NTHR = 64 * WM * WN, P = 60 * WN;
+    constexpr int H1 = 30 * WN + 40, LD1 = 2 * H1;      // staged input row (de-interleaved by conv1's dilation)
+    constexpr int H2 = 30 * WN + 16, LD2 = 2 * H2;      // parked intermediate row (de-interleaved, dilation 1)
+    constexpr int RI = (P + MAX_HALO + NTHR - 1) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const t1 = smem;                             // aliases the staging buffers (dead after phase 1)
+    const TileId t = map_tile(nx, 1, G.B * G.n);
+    if (!t.valid) return;
+    const int gi = t.bz / G.B, b = t.bz - gi * G.B;
+    const ResLayerArgs& a = ((const ResLayerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[gi];
+    const int d = a.dil1;
+    const int h1 = d * (a.k1 - 1) / 2, h2 = (a.k2 - 1) / 2;
+    const int NT = P - 2 * h2;
+    const int len = seg_len(G.seg, b);
+    const int n0 = t.bx * NT;
+    if (n0 >= len) return;
+    const size_t base = (size_t)seg_start(G.seg, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int m0 = wm * 32;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    constexpr int nchunk = C / CK;
+    const unsigned a_voff = (unsigned)((half * C + m0 + l31) * 4);
+    constexpr unsigned xi_stride = (unsigned)(C * C * 4);
+    float X[4][4], fa[4][4];
+
+    // ================= phase 1 =================
+    {
+        int n3, n2; wino_split(a.k1, &n3, &n2);
+        const int nseg = n3 + n2, nsteps = nchunk * 2 * nseg;
+        const rsrc_t wrs = make_rsrc(a.wu1, (unsigned)(nseg * 4 * C * C * 4));
+        auto load_a = [&](int c, int h, int sg, int xi, float (&dst)[4]) {
+            const unsigned sbase = ((unsigned)sg * 4u + (unsigned)xi) * xi_stride + (unsigned)((c * CK + h * 8) * C) * 4u;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                dst[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, (int)a_voff, (int)(sbase + (unsigned)(2 * p * C * 4)), 0));
+        };
+        auto load_xv = [&](int bufi, int h, int sg) {
+            const int j0 = sg < n3 ? 3 * sg : 3 * n3 + 2 * (sg - n3);
+            const float* sb = smem + bufi * (CK * LD1) + (h * 8 + half) * LD1 + 30 * wn + l31;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int j = j0 + m;
+                const float* sm = sb + (j & 1) * H1 + d * (j >> 1);
+#pragma unroll
+                for (int p = 0; p < 4; p++) X[m][p] = sm[2 * p * LD1];
+            }
+        };
+        const int Wneed = P + (a.k1 - 1) * d;
+        const int w0 = n0 - h2 - h1;
+        unsigned xoff[RI]; int lidx[RI]; bool act[RI];
+#pragma unroll
+        for (int i = 0; i < RI; i++) {
+            const int p = tid + i * NTHR;
+            const int pos = w0 + p;
+            act[i] = p < Wneed;
+            xoff[i] = (act[i] && pos >= 0 && pos < len) ? (unsigned)pos * 4u : kOOB;
+            const int q = p / (2 * d), rem = p - q * 2 * d, e = rem >= d ? 1 : 0;
+            lidx[i] = e * H1 + d * q + (rem - e * d);
+        }
+        float xr[8][RI];
+        auto load_x = [&](int c, int hh) {
+#pragma unroll
+            for (int i = 0; i < RI; i++)
+                if (act[i]) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                        xr[r][i] = buf_load(make_rsrc(a.x + (size_t)(c * CK + hh * 8 + r) * G.ld + base, (unsigned)len * 4u), xoff[i]);
+                }
+        };
+        auto store_x = [&](int bufi, int hh) {
+            float* sb = smem + bufi * (CK * LD1) + hh * 8 * LD1;
+#pragma unroll
+            for (int i = 0; i < RI; i++)
+                if (act[i]) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { const float v = xr[r][i]; sb[r * LD1 + lidx[i]] = v < 0.f ? v * G.slope : v; }
+                }
+        };
+        int sc = 0, sh = 0, ss = 0;
+        load_x(0, 0); store_x(0, 0);
+        load_x(0, 1); store_x(0, 1);
+        load_a(0, 0, 0, 0, fa[0]);
+        load_a(0, 0, 0, 1, fa[1]);
+        load_a(0, 0, 0, 2, fa[2]);
+        __syncthreads();
+        load_xv(0, 0, 0);
+        if (nchunk > 1) load_x(1, 0);
+        for (int s = 0; s < nsteps; s++) {
+            int ns = ss + 1, nh = sh, nc = sc;
+            if (ns == nseg) { ns = 0; nh = sh + 1; if (nh == 2) { nh = 0; nc = sc + 1; } }
+            const bool more = s + 1 < nsteps;
+            const bool three = ss < n3;
+            float v[4];
+            if (three) load_a(sc, sh, ss, 3, fa[3]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[0][p] - X[2][p];
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][p], v[p], acc[0], 0, 0, 0);
+            if (more) load_a(nc, nh, ns, 0, fa[0]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[1][p] + X[2][p];
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][p], v[p], acc[1], 0, 0, 0);
+            if (more) load_a(nc, nh, ns, 1, fa[1]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[2][p] - X[1][p];
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2][p], v[p], acc[2], 0, 0, 0);
+            if (more) load_a(nc, nh, ns, 2, fa[2]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[1][p] - X[3][p];
+            if (more) {
+                if (nc != sc) {
+                    store_x(nc & 1, 1);
+                    __syncthreads();
+                    if (nc + 1 < nchunk) load_x(nc + 1, 0);
+                } else if (nh != sh) {
+                    if (sc + 1 < nchunk) { store_x((sc + 1) & 1, 0); load_x(sc + 1, 1); }
+                }
+                load_xv(nc & 1, nh, ns);
+            }
+            if (three) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3][p], v[p], acc[3], 0, 0, 0);
+            }
+            ss = ns; sh = nh; sc = nc;
+        }
+    }
+    // park the intermediate (output transform, bias, conv2's input activation, conv2's zero padding)
+    __syncthreads();
+    {
+        const int q = l31 / d, rr = l31 - q * d;
+        const int pa = 60 * wn + 2 * d * q + rr, pb = pa + d;
+        const int ga = n0 - h2 + pa, gb = n0 - h2 + pb;
+        const bool ia = ga >= 0 && ga < len, ib = gb >= 0 && gb < len;
+        if (l31 < 30) {
+            static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float bv = a.b1 ? a.b1[row] : 0.f;
+                float ya = acc[0][r] + acc[1][r] + acc[2][r] + bv;
+                float yb = acc[1][r] - acc[2][r] - acc[3][r] + bv;
+                ya = ya < 0.f ? ya * G.slope : ya;
+                yb = yb < 0.f ? yb * G.slope : yb;
+                t1[row * LD2 + (pa & 1) * H2 + (pa >> 1)] = ia ? ya : 0.f;
+                t1[row * LD2 + (pb & 1) * H2 + (pb >> 1)] = ib ? yb : 0.f;
+            });
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    }
+    __syncthreads();
+
+    // ================= phase 2 =================
+    {
+        int n3, n2; wino_split(a.k2, &n3, &n2);
+        const int nseg = n3 + n2, nsteps = nchunk * 2 * nseg;
+        const rsrc_t wrs = make_rsrc(a.wu2, (unsigned)(nseg * 4 * C * C * 4));
+        auto load_a = [&](int c, int h, int sg, int xi, float (&dst)[4]) {
+            const unsigned sbase = ((unsigned)sg * 4u + (unsigned)xi) * xi_stride + (unsigned)((c * CK + h * 8) * C) * 4u;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                dst[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, (int)a_voff, (int)(sbase + (unsigned)(2 * p * C * 4)), 0));
+        };
+        auto load_xv = [&](int c, int h, int sg) {
+            const int j0 = sg < n3 ? 3 * sg : 3 * n3 + 2 * (sg - n3);
+            const float* sb = t1 + (c * CK + h * 8 + half) * LD2 + 30 * wn + l31;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int j = j0 + m;
+                const float* sm = sb + (j & 1) * H2 + (j >> 1);
+#pragma unroll
+                for (int p = 0; p < 4; p++) X[m][p] = sm[2 * p * LD2];
+            }
+        };
+        int sc = 0, sh = 0, ss = 0;
+        load_a(0, 0, 0, 0, fa[0]);
+        load_a(0, 0, 0, 1, fa[1]);
+        load_a(0, 0, 0, 2, fa[2]);
+        load_xv(0, 0, 0);
+        for (int s = 0; s < nsteps; s++) {
+            int ns = ss + 1, nh = sh, nc = sc;
+            if (ns == nseg) { ns = 0; nh = sh + 1; if (nh == 2) { nh = 0; nc = sc + 1; } }
+            const bool more = s + 1 < nsteps;
+            const bool three = ss < n3;
+            float v[4];
+            if (three) load_a(sc, sh, ss, 3, fa[3]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[0][p] - X[2][p];
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][p], v[p], acc[0], 0, 0, 0);
+            if (more) load_a(nc, nh, ns, 0, fa[0]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[1][p] + X[2][p];
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][p], v[p], acc[1], 0, 0, 0);
+            if (more) load_a(nc, nh, ns, 1, fa[1]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[2][p] - X[1][p];
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2][p], v[p], acc[2], 0, 0, 0);
+            if (more) load_a(nc, nh, ns, 2, fa[2]);
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = X[1][p] - X[3][p];
+            if (more) load_xv(nc, nh, ns);
+            if (three) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3][p], v[p], acc[3], 0, 0, 0);
+            }
+            ss = ns; sh = nh; sc = nc;
+        }
+    }
+    if (l31 < 30) {
+        const int oa = 60 * wn + 2 * l31, ob = oa + 1;
+        const bool va = oa < NT && n0 + oa < len, vb = ob < NT && n0 + ob < len;
+        const size_t opos = base + (size_t)(n0 + oa);
+        static_for<0, 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float bv = a.b2 ? a.b2[row] : 0.f;
+            const float ya = acc[0][r] + acc[1][r] + acc[2][r] + bv;
+            const float yb = acc[1][r] - acc[2][r] - acc[3][r] + bv;
+            const size_t o = (size_t)row * G.ld + opos;
+            if (va) a.y[o] = ya + a.x[o];
+            if (vb) a.y[o + 1] = yb + a.x[o + 1];
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // split-K matrix-core kernel for LATENCY-bound shapes (batch-1 text encoder / flow / duration
 // predictor: N = 128..700 positions, a few dozen output tiles, K up to 2304).  The LDS-staged kernel
 // above would run such a conv on a handful of CUs as one long dependent chain of global-load round
@@ -1078,6 +1324,41 @@ void wino_pack(const float* w, long s_out, long s_tap, long s_in, int Cout, int 
                 for (int xi = 0; xi < 4; xi++) dst[((size_t)sg * 4 + xi) * slab + (size_t)ci * Cout_pad + o] = (float)u[xi];
             }
     }
+}
+
+bool resblock_wino_eligible(const ResLayerGroup& G) {
+    if (!resblock_layer_eligible(G)) return false;
+    for (int i = 0; i < G.n; i++) {
+        const ResLayerArgs& a = G.g[i];
+        if (!a.wu1 || !a.wu2 || a.k1 < 2 || a.k2 < 2 || a.k2 > 15) return false;
+        if (a.dil1 < 1 || a.dil1 > 6 || 30 % a.dil1 != 0 || (a.k1 - 1) * a.dil1 > MAX_HALO) return false;
+    }
+    return true;
+}
+
+template <int WM, int WN>
+static void launch_resblock_wino(const ResLayerGroup& G, hipStream_t st) {
+    constexpr int P = 60 * WN, LD1 = 2 * (30 * WN + 40), LD2 = 2 * (30 * WN + 16);
+    int nx = 0;
+    for (int i = 0; i < G.n; i++) {
+        const int NT = P - (G.g[i].k2 - 1);
+        const int n = (G.max_n + NT - 1) / NT;
+        if (n > nx) nx = n;
+    }
+    const size_t stage = (size_t)2 * CK * LD1, park = (size_t)32 * WM * LD2 + 64;
+    const size_t lds = (stage > park ? stage : park) * sizeof(float);
+    hipLaunchKernelGGL((resblock_wino_kernel<WM, WN>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx);
+}
+
+void resblock_wino(const ResLayerGroup& Gin, hipStream_t st) {
+    ResLayerGroup G = Gin;
+    for (int i = 1; i < G.n; i++)                       // longest K loops first
+        for (int j = i; j > 0 && G.g[j].k1 + G.g[j].k2 > G.g[j - 1].k1 + G.g[j - 1].k2; j--) {
+            ResLayerArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
+        }
+    if (G.C == 32) launch_resblock_wino<1, 4>(G, st);
+    else if (G.C == 64) launch_resblock_wino<2, 2>(G, st);
+    else launch_resblock_wino<4, 2>(G, st);
 }
 
 bool conv_group_eligible(const ConvGroup& G) {

@@ -509,7 +509,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce;
                     float* nxt = (cur[j] == pa) ? pb : pa;
                     R.g[j].x = cur[j]; R.g[j].y = nxt; R.g[j].w1 = c1.w; R.g[j].b1 = c1.bias; R.g[j].w2 = c2.w; R.g[j].b2 = c2.bias;
-                    R.g[j].k1 = c1.k; R.g[j].dil1 = c1.dil; R.g[j].k2 = c2.k;
+                    R.g[j].k1 = c1.k; R.g[j].dil1 = c1.dil; R.g[j].k2 = c2.k; R.g[j].wu1 = c1.wu; R.g[j].wu2 = c2.wu;
                 }
                 // the 128-channel variant runs 8-wave workgroups, two per CU: only worth it when the grid fills the chip twice
                 if (fuse && R.C > 64) fuse = (long)((l2.max_len + 117) / 118) * l2.nb * nk >= 512;
@@ -523,7 +523,11 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                         (void)conv_args(rb.c2[d], cur[j], l2, R.g[j].y, l2, o2, &f); fl += f;
                         cur[j] = R.g[j].y;
                     }
-                    resblock_layer(R, stream);
+                    // both convs in the Winograd domain when the model carries the transformed weights (-31 % MFMAs);
+                    // the direct-form fused kernel otherwise
+                    static const bool no_wino = getenv("STS_NO_WINO") != nullptr;   // experiment knob
+                    if (!no_wino && resblock_wino_eligible(R)) resblock_wino(R, stream);
+                    else resblock_layer(R, stream);
                     mfma_flops_ += fl; mfma_launches_ += 1;
                     continue;
                 }

@@ -56,7 +56,7 @@ struct ConvArgs {
 // Segmented Winograd F(2,3): a k-tap filter is cut into n3 three-tap segments followed by n2 two-tap segments
 // (k = 3 n3 + 2 n2, n2 in {0,1,2}); every segment contributes 4 (3-tap) or 3 (2-tap) products per pair of
 // outputs instead of 6 / 4, and all segments accumulate into the same four Winograd-domain sums.
-inline void wino_split(int k, int* n3, int* n2) { *n2 = (k % 3 == 0) ? 0 : (k % 3 == 2 ? 1 : 2); *n3 = (k - 2 * *n2) / 3; }
+__host__ __device__ inline void wino_split(int k, int* n3, int* n2) { *n2 = (k % 3 == 0) ? 0 : (k % 3 == 2 ? 1 : 2); *n3 = (k - 2 * *n2) / 3; }
 // w: [Cout][k][Cin] source order (or any accessor order given by the strides), dst: [seg][4][Cin_pad][Cout_pad]
 void wino_pack(const float* w, long s_out, long s_tap, long s_in, int Cout, int k, int Cin, int Cin_pad, int Cout_pad, float* dst);
 bool conv_wino_eligible(const ConvArgs& a);
@@ -97,6 +97,7 @@ struct ResLayerArgs {
     const float* x; float* y;                 // [C][ld], distinct buffers
     const float *w1, *b1, *w2, *b2;           // packed [k][C][C] (cout contiguous), biases may be null
     int k1, dil1, k2;
+    const float *wu1, *wu2;                   // Winograd-domain copies [seg][4][C][C] (wino_pack) or null
 };
 struct ResLayerGroup {
     ResLayerArgs g[kMaxGroup];                // must stay the first member (indexed through the kernarg pointer)
@@ -105,6 +106,9 @@ struct ResLayerGroup {
 };
 bool resblock_layer_eligible(const ResLayerGroup& G);
 void resblock_layer(const ResLayerGroup& G, hipStream_t st);
+// the same layer with both convs in the Winograd domain (segmented F(2,3), see conv_wino_body)
+bool resblock_wino_eligible(const ResLayerGroup& G);
+void resblock_wino(const ResLayerGroup& G, hipStream_t st);
 bool conv_group_eligible(const ConvGroup& G);
 void conv_mfma_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 void conv_generic(const ConvArgs& a, hipStream_t st);

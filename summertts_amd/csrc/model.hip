@@ -1,6 +1,7 @@
 // model.hip -- blob parser + weight repacker (see model.hpp).  Host code; compiled by hipcc for the
 // HIP runtime calls only.
 #include "model.hpp"
+#include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -113,6 +114,20 @@ bool pack_conv(Store& st, const HConv& h, const PackOpts& o, DConv& d) {
         if (!b) return false;
         for (int pr = 0; pr < d.Cout_pad; pr++) { const int sr = src_row(pr); if (sr >= 0) b[pr] = h.b[sr]; }
     }
+    return true;
+}
+
+// Winograd-domain copy U = G g of a plain conv's weights (kernels.hpp: wino_pack) for resblock_wino_kernel;
+// only the ResBlock convs of the <= 128-channel decoder stages get one (the kernel's LDS tile bounds C)
+bool pack_wino(Store& st, const HConv& h, DConv& d) {
+    if (d.depthwise || d.transposed || h.k < 2 || h.k > 15 || d.Cin != d.Cout || d.Cin != d.Cin_pad || d.Cout != d.Cout_pad) return true;
+    if (d.Cin != 32 && d.Cin != 64 && d.Cin != 128) return true;
+    if (h.dil < 1 || h.dil > 6 || 30 % h.dil != 0 || (h.k - 1) * h.dil > 64) return true;
+    int n3, n2; wino_split(h.k, &n3, &n2);
+    const size_t n = (size_t)(n3 + n2) * 4 * d.Cin_pad * d.Cout_pad;
+    float* u = st.alloc(n, &d.wu);
+    if (!u) { d.wu = nullptr; return false; }
+    wino_pack(h.w, (long)h.k * h.in_ch, h.in_ch, 1, d.Cout, h.k, d.Cin, d.Cin_pad, d.Cout_pad, u);
     return true;
 }
 
@@ -314,8 +329,8 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         const int n = r.geti();
         if (!r.ok || n <= 0 || n > 32) FAIL("resblock");
         rb.c1.resize(n); rb.c2.resize(n);
-        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i])) FAIL("resblock convs1"); }
-        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i])) FAIL("resblock convs2"); }
+        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i]) || !pack_wino(st, h, rb.c1[i])) FAIL("resblock convs1"); }
+        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i])) FAIL("resblock convs2"); }
     }
     { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_post)) FAIL("conv_post"); }
     if (m.dec_type == 0 && m.is_ms == 1) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.dec_cond)) FAIL("decoder cond"); }

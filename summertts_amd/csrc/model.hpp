@@ -30,6 +30,7 @@ struct DConv {
     int gate_perm = 0, H = 0;
     const float* w = nullptr;
     const float* bias = nullptr;
+    const float* wu = nullptr;      // Winograd-domain copy [seg][4][Cin_pad][Cout_pad] (narrow decoder ResBlock convs)
     double macs_per_out = 0;   // true-tap MACs per output position (all output channels)
 };
 struct DLn { int C = 0; const float* g = nullptr; const float* b = nullptr; };

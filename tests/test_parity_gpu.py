@@ -252,23 +252,31 @@ def test_malformed_blobs_are_rejected():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["hifigan_sdp", "mbb_fix", "ms_sdp", "istft_fix", "ms_hifigan_sdp"])
-def test_streaming_equals_one_pass_bit_exact(kind):
-    """sts_infer_ids_stream: chunks decoded with receptive-field halos concatenate to exactly the
-    one-pass PCM, for every decoder family, for chunk sizes below / around / above the halo."""
+def test_streaming_equals_one_pass(kind):
+    """sts_infer_ids_stream: chunks decoded with receptive-field halos concatenate to the one-pass
+    PCM for every decoder family and for chunk sizes below / around / above the halo: bit for bit with a pinned
+    kernel variant, within 1 LSB under the automatic choice (a chunk is a different launch size, and the
+    Winograd-domain layer kernel pairs output positions relative to the window start)."""
     cfg = sb.tiny_cfg(kind)
     blob = sb.make_blob(cfg, 99)
     syn = engine.Synthesizer(blob)
     ids = sb.synthetic_ids(41, cfg.vocab, salt=5)
     sid = 1 if cfg.is_ms else 0
-    full = syn.infer_ids(ids, sid=sid, length_scale=1.3)
     halo = syn.stream_halo_frames()
     assert 1 <= halo < 400
-    for chunk in (1, 7, halo, 3 * halo + 1, 100000):
-        chunks, times = syn.infer_ids_stream(ids, chunk, sid=sid, length_scale=1.3)
-        got = np.concatenate(chunks)
-        assert got.shape == full.shape, (kind, chunk, got.shape, full.shape)
-        assert np.array_equal(got, full), (kind, chunk, int(np.abs(got.astype(np.int32) - full).max()))
-        assert all(t1 >= t0 for t0, t1 in zip(times, times[1:]))
+    for mode in (0, 6):
+        syn.set_conv_mode(mode)
+        full = syn.infer_ids(ids, sid=sid, length_scale=1.3)
+        for chunk in (1, 7, halo, 3 * halo + 1, 100000):
+            chunks, times = syn.infer_ids_stream(ids, chunk, sid=sid, length_scale=1.3)
+            got = np.concatenate(chunks)
+            assert got.shape == full.shape, (kind, chunk, got.shape, full.shape)
+            if mode == 6:
+                assert np.array_equal(got, full), (kind, chunk, int(np.abs(got.astype(np.int32) - full).max()))
+            else:
+                assert_pcm_close(got, full, f"streamed vs one pass, {kind}, chunk {chunk}")
+            assert all(t1 >= t0 for t0, t1 in zip(times, times[1:]))
+    syn.set_conv_mode(0)
     # early stop from the callback
     chunks, _ = syn.infer_ids_stream(ids, 8, sid=sid, length_scale=1.3, on_chunk=lambda pcm, off, t: True)
     assert len(chunks) == 1
