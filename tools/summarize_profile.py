@@ -41,7 +41,7 @@ def main():
     st = newest(os.path.join(kt, "*", "*kernel_stats.csv"))
     shutil.copy(st, os.path.join(out, f"{tag}_kernel_stats.csv"))
     # the LDS-staged matrix-core conv: single (upsamplers), grouped (ResBlock chains) and fused-layer (narrow stages) forms
-    fam = ("conv_mfma_kernel", "conv_mfma_group_kernel", "resblock_layer_kernel")
+    fam = ("conv_mfma_kernel", "conv_mfma_group_kernel", "resblock_layer_kernel", "resblock_wino_kernel")
     rows = [r for r in csv.DictReader(open(st)) if any(f in r["Name"] for f in fam)]
     calls = sum(int(r["Calls"]) for r in rows)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
