@@ -1,0 +1,16 @@
+"""Actual error of the GPU path against the compiled reference at a realistic size (full-size HiFi-GAN model, 72
+phonemes), with the Winograd-domain layer kernels (default) and with the direct-form ones (STS_NO_WINO=1; the
+switch is read once per process, hence two runs):   python tools/err_check.py; STS_NO_WINO=1 python tools/err_check.py"""
+import numpy as np, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyref
+from summertts_amd import engine, synth_blob as sb
+
+cfg = sb.full_cfg("hifigan_sdp"); blob = sb.make_blob(cfg, 1234)
+ids = sb.synthetic_ids(72, cfg.vocab, salt=3)
+o = pyref.RefModel(blob).infer_ids(ids, 0, 1.0)
+syn = engine.Synthesizer(blob); syn.set_record_taps(True); syn.run_batch([ids])
+w = syn.tap("wave")[0]; d = w - o["wave"]
+p = syn.pcm_host().astype(np.int32) - o["pcm"].astype(np.int32)
+print("direct  " if os.environ.get("STS_NO_WINO") else "winograd", "wave rmse %.2e max %.2e (ref rms %.3f) | pcm max %d LSB on %d of %d" % (
+    np.sqrt((d * d).mean()), np.abs(d).max(), o["wave"].std(), np.abs(p).max(), (p != 0).sum(), p.size))
