@@ -133,6 +133,12 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
 void sts_free(void* p);
 const char* sts_last_error(void);
 
+/* Host-only diagnostic: the Winograd-domain weight transform the loader applies to the decoder's ResBlock convs
+ * (segmented F(2,3), summertts_amd/csrc/kernels.hpp: wino_pack).  w is [Cout][k][Cin] (the blob's order); out must
+ * hold n_seg * 4 * Cin_pad * Cout_pad floats, laid out [seg][4][Cin_pad][Cout_pad] (Cin_pad = Cin rounded up to 16,
+ * Cout_pad to 32).  Returns n_seg (>= 1) or a negative STS_E* code.  No GPU needed. */
+int sts_debug_wino_pack(const float* w, int32_t Cout, int32_t k, int32_t Cin, float* out, int64_t out_floats);
+
 /* ---- request pool (no reference counterpart: SynthesizerTrn::infer is one blocking call per
  * utterance, SynthesizerTrn.cpp:323).  n_engines engines on one GPU, one worker thread each, one FIFO; a free
  * worker folds up to max_batch queued requests into ONE packed variable-length batch.  submit() returns a

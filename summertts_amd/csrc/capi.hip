@@ -159,6 +159,15 @@ int sts_get_durations(sts_engine* e, int32_t* dur, int64_t cap) {
 
 // ------------------------------------------------------------------------------------------------
 // op-level entry for the parity tests: one conv on host arrays through the same kernels
+int sts_debug_wino_pack(const float* w, int32_t Cout, int32_t k, int32_t Cin, float* out, int64_t out_floats) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || k < 2) return set_err(STS_EINVAL, "bad arguments");
+    int n3, n2; wino_split(k, &n3, &n2);
+    const int Cin_pad = (Cin + 15) / 16 * 16, Cout_pad = (Cout + 31) / 32 * 32;
+    if (out_floats < (int64_t)(n3 + n2) * 4 * Cin_pad * Cout_pad) return set_err(STS_EINVAL, "output buffer too small");
+    wino_pack(w, (long)k * Cin, Cin, 1, Cout, k, Cin, Cin_pad, Cout_pad, out);
+    return n3 + n2;
+}
+
 int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias, int32_t Cout,
                      int32_t k, int32_t pad, int32_t dil, int32_t stride_t, int32_t depthwise, float in_slope, int32_t in_act,
                      int mode, float** y_out, int32_t* Lout_out) {

@@ -87,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_profiling",
     "sts_get_profile", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
-    "sts_infer_ids_stream", "sts_stream_halo_frames",
+    "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
 ]
 
@@ -246,6 +246,20 @@ def debug_conv1d(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], pad: 
     out = np.ctypeslib.as_array(y, shape=(cout, lout.value)).copy()
     lib.sts_free(y)
     return (out, float(ms.value)) if iters > 0 else out
+
+
+def debug_wino_pack(w: np.ndarray) -> np.ndarray:
+    """Winograd-domain transform of conv weights w[Cout][k][Cin] -> U[seg][4][Cin_pad][Cout_pad] (host only)."""
+    lib = load_library()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    co, k, ci = w.shape
+    cip, cop = (ci + 15) // 16 * 16, (co + 31) // 32 * 32
+    nseg = {0: k // 3, 2: (k - 2) // 3 + 1, 1: (k - 4) // 3 + 2}[k % 3]
+    out = np.zeros((nseg, 4, cip, cop), np.float32)
+    rc = lib.sts_debug_wino_pack(w.ctypes.data_as(C.c_void_p), co, k, ci, out.ctypes.data_as(C.c_void_p), C.c_int64(out.size))
+    if rc != nseg:
+        raise StsError(f"sts_debug_wino_pack: {rc}")
+    return out
 
 
 class Pool:

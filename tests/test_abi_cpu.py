@@ -63,3 +63,38 @@ def test_product_never_touches_the_oracle():
                 assert "vits_oracle" not in txt and "libsummertts_ref" not in txt and "pyref" not in txt, os.path.join(dirpath, f)
     ldd = subprocess.run(["ldd", engine.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in ldd
+
+
+@pytest.mark.parametrize("k,dil", [(3, 1), (5, 2), (7, 3), (11, 5), (13, 1), (2, 1), (4, 1)])
+def test_winograd_weight_transform_reproduces_the_direct_conv(k, dil):
+    """Host logic of the Winograd-domain layer kernels: the packed U = G g (segmented F(2,3), 3-tap segments first,
+    then 2-tap ones) pushed through the kernel's arithmetic -- per segment M0 += U0 (X0 - X2), M1 += U1 (X1 + X2),
+    M2 += U2 (X2 - X1), M3 += U3 (X1 - X3); y[n] = M0 + M1 + M2, y[n + d] = M1 - M2 - M3 -- equals the direct conv."""
+    from summertts_amd import engine
+    rng = np.random.default_rng(k * 10 + dil)
+    co, ci, npairs = 5, 3, 40
+    w = rng.standard_normal((co, k, ci)).astype(np.float32)
+    U = engine.debug_wino_pack(w).astype(np.float64)          # [seg][4][16][32]
+    n3 = {0: k // 3, 2: (k - 2) // 3, 1: (k - 4) // 3}[k % 3]
+    nseg = U.shape[0]
+    assert nseg == n3 + {0: 0, 2: 1, 1: 2}[k % 3] and U.shape[1:] == (4, 16, 32)
+    assert not U[:, :, ci:, :].any() and not U[:, :, :, co:].any()                      # padding stays zero
+    L = 2 * dil * npairs
+    x = rng.standard_normal((ci, L + (k + 1) * dil))
+    direct = np.zeros((co, L))
+    for j in range(k):
+        direct += w[:, j, :].astype(np.float64) @ x[:, j * dil:j * dil + L]
+    n = np.arange(L).reshape(-1, 2, dil)[:, 0, :].reshape(-1)     # first position of every output pair
+    M = [np.zeros((co, n.size)) for _ in range(4)]
+    for sg in range(nseg):
+        j0 = 3 * sg if sg < n3 else 3 * n3 + 2 * (sg - n3)
+        X = [x[:, n + (j0 + m) * dil] for m in range(4)]
+        V = [X[0] - X[2], X[1] + X[2], X[2] - X[1], X[1] - X[3]]
+        for xi in range(4 if sg < n3 else 3):
+            M[xi] += U[sg, xi, :ci, :co].T @ V[xi]
+        if sg >= n3:
+            assert not U[sg, 3].any()                                                       # 2-tap segment: no fourth product
+    got = np.zeros((co, L))
+    got[:, n] = M[0] + M[1] + M[2]
+    got[:, n + dil] = M[1] - M[2] - M[3]
+    assert np.abs(got - direct).max() < 1e-5
