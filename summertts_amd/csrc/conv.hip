@@ -886,22 +886,22 @@ void resblock_wino_kernel(ResLayerGroup G, int nx) {
             const bool more = s + 1 < nsteps;
             const bool three = ss < n3;
             float v[4];
-            if (three) load_a(sc, sh, ss, 3, fa[3]);
+            load_a(sc, sh, ss, 3, fa[3]);      // unconditional (a 2-tap segment's fourth slab is zeros and is not multiplied)
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[0][p] - X[2][p];
 #pragma unroll
             for (int p = 0; p < 4; p++) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][p], v[p], acc[0], 0, 0, 0);
-            if (more) load_a(nc, nh, ns, 0, fa[0]);
+            load_a(nc, nh, ns, 0, fa[0]);      // past the last step these read inside the descriptor and are never used
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[1][p] + X[2][p];
 #pragma unroll
             for (int p = 0; p < 4; p++) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][p], v[p], acc[1], 0, 0, 0);
-            if (more) load_a(nc, nh, ns, 1, fa[1]);
+            load_a(nc, nh, ns, 1, fa[1]);
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[2][p] - X[1][p];
 #pragma unroll
             for (int p = 0; p < 4; p++) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2][p], v[p], acc[2], 0, 0, 0);
-            if (more) load_a(nc, nh, ns, 2, fa[2]);
+            load_a(nc, nh, ns, 2, fa[2]);
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[1][p] - X[3][p];
             if (more) {
@@ -981,25 +981,25 @@ void resblock_wino_kernel(ResLayerGroup G, int nx) {
             const bool more = s + 1 < nsteps;
             const bool three = ss < n3;
             float v[4];
-            if (three) load_a(sc, sh, ss, 3, fa[3]);
+            load_a(sc, sh, ss, 3, fa[3]);      // unconditional (a 2-tap segment's fourth slab is zeros and is not multiplied)
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[0][p] - X[2][p];
 #pragma unroll
             for (int p = 0; p < 4; p++) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][p], v[p], acc[0], 0, 0, 0);
-            if (more) load_a(nc, nh, ns, 0, fa[0]);
+            load_a(nc, nh, ns, 0, fa[0]);      // past the last step these read inside the descriptor and are never used
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[1][p] + X[2][p];
 #pragma unroll
             for (int p = 0; p < 4; p++) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][p], v[p], acc[1], 0, 0, 0);
-            if (more) load_a(nc, nh, ns, 1, fa[1]);
+            load_a(nc, nh, ns, 1, fa[1]);
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[2][p] - X[1][p];
 #pragma unroll
             for (int p = 0; p < 4; p++) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2][p], v[p], acc[2], 0, 0, 0);
-            if (more) load_a(nc, nh, ns, 2, fa[2]);
+            load_a(nc, nh, ns, 2, fa[2]);
 #pragma unroll
             for (int p = 0; p < 4; p++) v[p] = X[1][p] - X[3][p];
-            if (more) load_xv(nc, nh, ns);
+            load_xv(more ? nc : 0, nh, ns);
             if (three) {
 #pragma unroll
                 for (int p = 0; p < 4; p++) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3][p], v[p], acc[3], 0, 0, 0);
