@@ -235,9 +235,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
         const bool last_tap = sj + 1 == a.ntap;
         int nj = sj + 1, nc = sc;
         if (last_tap) { nj = 0; nc = sc + 1; }
-        if (s + 2 < nsteps) request_a(anew);
-        if (s + 1 < nsteps) {
-            if (last_tap) {
+        // the prefetches are unconditional: past the last step they read inside the weight descriptor / the LDS
+        // tile and are never used (predicated loads would cost register merges in the steady state)
+        request_a(anew);
+        {
+            if (last_tap && s + 1 < nsteps) {
                 // chunk boundary: this step's B fragment is already in registers, so the next tile can be
                 // published before this step's MFMAs issue
                 store_tile(nc & 1);          // chunk nc's tile (in registers since the start of chunk sc)
