@@ -11,13 +11,22 @@ A *step* is one pass of the hot path (phoneme ids -> int16 PCM on the host) over
 every rank runs its own shard of the utterance batch (per-GPU work fixed: weak scaling, no data-path
 collective) and the int16 PCM is gathered to rank 0 over RCCL inside the timed step.
 
+``--gpus N`` with N > 1: when the script was not started by torchrun (no WORLD_SIZE in the environment) it
+launches the N ranks itself -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+127.0.0.1 -- and relays rank 0's JSON line.  Started under ``python -m torch.distributed.run`` it uses the
+environment it is given.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,13 +39,72 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(blob, cfg, vocab, sample_T):
-    """Times the reference (oracle/_ref, the real Eigen path) or, failing that, the C restatement on
-    a bounded sample of the same workload on this box's host cores."""
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` == N ranks, one per GPU
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv, timeout_s: float = 3000.0) -> int:
+    """Starts n copies of this script (ranks 0..n-1) and relays rank 0's stdout.  Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "STS_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    rc = 0
+    out0 = ""
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout_s)
+        rc = procs[0].returncode
+        for p in procs[1:]:
+            p.wait(timeout=120)
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:                       # exact PIDs we started, nothing else
+            if p.poll() is None:
+                p.kill()
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)          # the JSON line stays the last thing on stdout
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY.md 8d protocol)
+# ------------------------------------------------------------------------------------------------
+def _set_omp_threads(n: int) -> bool:
+    """Eigen's GEMM parallelizer asks omp_get_max_threads() on every call, so the thread count can be changed in-process."""
+    import ctypes
+    for name in ("libgomp.so.1", "libgomp.so"):
+        try:
+            ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL).omp_set_num_threads(int(n))
+            return True
+        except OSError:
+            continue
+    return False
+
+
+def cpu_baseline(blob, vocab, ids, reps: int, sweep):
+    """The reference itself (oracle/_ref: the real Eigen path compiled with the reference's flags) or, failing that,
+    the C restatement, on this box's host cores: the SAME blob and the SAME phoneme ids as the GPU step, one warm-up
+    (pays the OpenMP start-up) then `reps` timed repetitions -> median; the thread count is the best of `sweep`,
+    chosen once on a short utterance."""
     from oracle import pyref
     from summertts_amd import synth_blob as sb
-    kind = None
-    model = None
     if pyref.have_ref():
         model, kind = pyref.RefModel(blob), "reference"
     else:
@@ -44,18 +112,56 @@ def cpu_baseline(blob, cfg, vocab, sample_T):
             model, kind = pyref.PortModel(blob), "port"
         except Exception:
             return None
-    ids_w = sb.synthetic_ids(6, vocab)
-    model.infer_ids(ids_w, 0, 1.0)            # warm-up: pays the OpenMP start-up
-    ids = sb.synthetic_ids(sample_T, vocab)
-    t0 = time.perf_counter()
-    out = model.infer_ids(ids, 0, 1.0)
-    dt = time.perf_counter() - t0
-    n = int(out["wave"].size)
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": n / dt, "unit": "samples/s", "cores": cores, "kind": kind,
-            "sample": f"1 utterance, {sample_T} phonemes -> {n} samples in {dt:.2f} s "
-                      f"(same blob; {'reference Eigen path, -O3 -fopenmp' if kind == 'reference' else 'C restatement, OpenMP'})",
-            "x_realtime": n / dt / 16000.0}
+    nproc = os.cpu_count() or 1
+    probe = sb.synthetic_ids(12, vocab, salt=1)
+    model.infer_ids(sb.synthetic_ids(6, vocab), 0, 1.0)            # warm-up: OpenMP thread pool, page-in
+    sweep_res = {}
+    best_t = None
+    if os.environ.get("OMP_NUM_THREADS"):
+        best_t = int(os.environ["OMP_NUM_THREADS"])
+    else:
+        cands = sorted({min(t, nproc) for t in sweep})
+        for t in cands:
+            if not _set_omp_threads(t):
+                break
+            model.infer_ids(probe, 0, 1.0)
+            t0 = time.perf_counter()
+            o = model.infer_ids(probe, 0, 1.0)
+            sweep_res[t] = int(o["wave"].size) / (time.perf_counter() - t0)
+        if sweep_res:
+            best_t = max(sweep_res, key=sweep_res.get)
+            _set_omp_threads(best_t)
+        else:
+            best_t = nproc
+    model.infer_ids(probe, 0, 1.0)                                  # warm-up at the chosen thread count
+    times, stages, n = [], [], 0
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        out = model.infer_ids(ids, 0, 1.0)
+        times.append(time.perf_counter() - t0)
+        stages.append(out["times"])
+        n = int(out["wave"].size)
+    med = float(np.median(times))
+    st = stages[int(np.argsort(times)[len(times) // 2])]
+    return {"value": n / med, "unit": "samples/s", "x_realtime": n / med / 16000.0, "cores": int(best_t), "nproc": nproc,
+            "kind": kind, "phonemes": int(len(ids)), "reps": len(times), "seconds_per_rep_median": med,
+            "seconds_per_rep_all": [round(t, 3) for t in times],
+            "thread_sweep_samples_per_s": {str(k): round(v, 1) for k, v in sweep_res.items()},
+            "stage_seconds": {k: round(float(v), 4) for k, v in st.items()},
+            "sample": f"{len(times)} x 1 utterance of {len(ids)} phonemes (the GPU step's blob and ids) -> {n} samples, "
+                      f"median {med:.2f} s, {best_t} OpenMP threads of {nproc} host CPUs "
+                      f"({'reference Eigen path, -O3 -fopenmp -std=c++11' if kind == 'reference' else 'C restatement, OpenMP'})"}
+
+
+def kernel_build_id() -> str:
+    """sha256 over the kernel sources: ties a committed PMC summary to the library it was measured with."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "summertts_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -65,40 +171,59 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="hifigan_sdp",
                     help="synthetic stand-in for single_speaker_fast.bin: hifigan_sdp (VITS HiFi-GAN + stochastic DP, "
-                         "the heavier reading) | mbb_fix | ms_fix | istft_fix | ms_hifigan_sdp")
+                         "the heavier reading) | mbb_fix | ms_fix | ms_sdp | istft_fix | ms_hifigan_sdp")
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
     ap.add_argument("--phonemes", type=int, default=128)
     ap.add_argument("--ragged", action="store_true",
                     help="utterance lengths ~ U{64..256} (seed 1234) instead of --phonemes each (BASELINE configs[2..4])")
-    ap.add_argument("--cpu-sample-phonemes", type=int, default=24)
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU baseline (median reported)")
+    ap.add_argument("--cpu-threads", default="8,16,32,64", help="OpenMP thread counts tried once for the CPU baseline")
+    ap.add_argument("--cpu-sample-phonemes", type=int, default=0, help="0 = the GPU step's utterance (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=0)
     ap.add_argument("--pipeline-engines", type=int, default=2,
                     help="extra (not the headline): throughput with this many engines fed by concurrent host threads, "
                          "so one utterance's latency-bound text side overlaps another's decoder; 0 disables")
+    ap.add_argument("--backend", default=os.environ.get("STS_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the PCM gather: nccl (= RCCL, the product path) | gloo (tests: the "
+                         "PCM goes through the host)")
+    ap.add_argument("--share-gpu", action="store_true", help="tests only: every rank uses device 0 (needs --backend gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
+    # the engine binding is looked up by name so that the launcher / gather path can be exercised on a machine without
+    # a GPU (tests/test_bench_launch_cpu.py runs `--gpus 2 --backend gloo` with tests/stub_engine.py)
+    eng = importlib.import_module(os.environ.get("STS_BENCH_ENGINE", "summertts_amd.engine"))
+    stub = getattr(eng, "IS_STUB", False)
     import torch
+    dev_index = 0 if (args.share_gpu or stub) else local_rank
+    use_cuda = not stub
     dist = None
-    force_dist = os.environ.get("STS_BENCH_FORCE_DIST") == "1"   # exercise the RCCL gather path on one GPU
+    force_dist = os.environ.get("STS_BENCH_FORCE_DIST") == "1"   # exercise the gather path with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from summertts_amd import engine as eng
     from summertts_amd import synth_blob as sb
     from summertts_amd import sharding
 
-    cfg = sb.full_cfg(args.workload)
+    cfg = sb.full_cfg(args.workload) if not stub else sb.tiny_cfg("hifigan_fix")
     blob = sb.make_blob(cfg, 1234)
-    syn = eng.Synthesizer(blob, device=local_rank if world > 1 else 0)
+    syn = eng.Synthesizer(blob, device=dev_index)
     syn.set_conv_mode(args.conv_mode)
 
     # global batch = world * batch utterances, sharded by utterance (no data-path collective)
@@ -115,25 +240,29 @@ def main():
     sid = [u % max(1, syn.get_speaker_num()) for u in mine]
     ls = [1.0] * len(ids)
 
-    # N > 1: the PCM gather of step k (count exchange + RCCL gather + download + unpack on rank 0) runs on a
+    # N > 1: the PCM gather of step k (count exchange + gather + download + unpack on rank 0) runs on a
     # helper thread while the main thread already synthesises step k + 1; every gather is completed before the
     # clock stops (drain()).  Collectives are issued by ONE thread per rank, in step order.
     gq = None
+    gather_busy = [0.0]
+    gathered = [0]
     if dist is not None:
         import queue
         import threading
         gq = queue.Queue()
-        gathered = [0]
 
         def gather_worker():
-            torch.cuda.set_device(local_rank)
+            if args.backend == "nccl":
+                torch.cuda.set_device(dev_index)
             while True:
                 item = gq.get()
                 if item is None:
                     gq.task_done()
                     return
                 local, counts = item
+                tg = time.perf_counter()
                 res = sharding.gather_variable(local, counts, dist, torch, rank, world, max_utts)
+                gather_busy[0] += time.perf_counter() - tg
                 if res is not None:
                     gathered[0] += sum(int(a_.size) for per_rank in res for a_ in per_rank)
                 gq.task_done()
@@ -141,13 +270,17 @@ def main():
         gth.start()
 
     def step():
-        n_out = syn.run_batch(ids, sid, ls)
+        n_out = sharding.run_shard(syn, ids, sid, ls)
+        total = int(n_out.sum()) if len(n_out) else 0
         if dist is None:
             pcm = syn.pcm_host()
-            return int(n_out.sum()), pcm
-        total = int(n_out.sum())
-        local = torch.empty(max(1, total), dtype=torch.int16, device="cuda")
-        syn.pcm_to_device_ptr(local.data_ptr(), local.numel())      # device-to-device; the engine is free again
+            return total, pcm
+        if args.backend == "nccl":
+            local = torch.empty(max(1, total), dtype=torch.int16, device="cuda")
+            if total:
+                syn.pcm_to_device_ptr(local.data_ptr(), local.numel())      # device-to-device; the engine is free again
+        else:
+            local = torch.from_numpy(syn.pcm_host().copy()) if total else torch.zeros(1, dtype=torch.int16)
         gq.put((local[:total], [int(v) for v in n_out]))
         return total, None
 
@@ -156,20 +289,22 @@ def main():
             gq.join()
 
     def sync():
-        torch.cuda.synchronize()
+        if use_cuda:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if use_cuda:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     drain()
     syn.set_profiling(True)
+    gather_busy[0] = 0.0
+    gathered[0] = 0
     sync()
     lat = []
-    mfma_ms = mfma_flops = dec_ms = dec_flops = dec_bytes = 0.0
-    launches = 0
-    stage_ms = np.zeros(4)
+    acc = {}
     samples = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,11 +312,11 @@ def main():
         n, _pcm = step()
         lat.append(time.perf_counter() - ts)
         samples += n
-        p = syn.profile()
-        mfma_ms += p["ms_decoder_mfma"]; mfma_flops += p["flops_decoder_mfma"]; launches += p["decoder_mfma_launches"]
-        dec_ms += p["ms_decoder"]; dec_flops += p["flops_decoder"]; dec_bytes += p["bytes_decoder_min"]
-        stage_ms += np.array([p["ms_text_encoder"], p["ms_duration"], p["ms_flow"], p["ms_decoder"]])
+        for k, v in syn.profile().items():
+            acc[k] = acc.get(k, 0.0) + float(v)
+    t_drain0 = time.perf_counter()
     drain()
+    drain_wait = time.perf_counter() - t_drain0
     sync()
     elapsed = time.perf_counter() - t0
     last = syn.profile()
@@ -190,7 +325,7 @@ def main():
     # one FIFO).  "pipelined" = batch-1 requests only overlapped across engines (max_batch 1); "burst" = the same
     # requests submitted at once with dynamic packed batching (max_batch 8).
     pipelined = None
-    if dist is None and args.pipeline_engines >= 2:
+    if dist is None and args.pipeline_engines >= 2 and not stub:
         nreq = max(8, args.steps)
         pipelined = {"engines": args.pipeline_engines, "requests": nreq}
         for label, mb in (("pipelined_batch1", 1), ("burst_max_batch8", 8)):
@@ -206,28 +341,60 @@ def main():
             pool.close()
 
     total_samples = samples
+    per_rank = [samples]
     if dist is not None:
-        t = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device="cuda")
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
         elapsed = float(tmax[0].item())
-        total_samples = int(tsum[1].item())
+        per_rank = [int(a_[1].item()) for a_ in allr]
+        total_samples = int(sum(per_rank))
 
-    # HBM traffic of the dominant kernel family comes from a separate rocprofv3 --pmc pass (the guide's
-    # recipe: FETCH_SIZE and WRITE_SIZE in their own runs), summarised by tools/summarize_profile.py
+    # HBM traffic / MFMA-busy of the dominant kernel family come from separate rocprofv3 --pmc passes (the guide's
+    # recipe: FETCH_SIZE and WRITE_SIZE in their own runs), summarised by tools/summarize_profile.py.  A summary is
+    # attached only when it was taken with THIS library build on THIS workload.
     traffic = None
+    pmc_extra = {}
+    wl_key = f"{args.workload}|batch={args.batch}|phonemes={args.phonemes}|ragged={int(args.ragged)}"
+    build_id = kernel_build_id()
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-        if args.workload == "hifigan_sdp" and args.batch == 1 and args.phonemes == 128 and not args.ragged:
-            traffic = {"hbm_bytes_per_launch": pmc["hbm_bytes_per_launch_corrected"], "source": "profiles/latest_pmc.json (" + pmc["tag"] + ")",
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        pmc = pmc_all.get("by_workload", {}).get(wl_key)
+        if pmc and pmc.get("kernel_build_id") == build_id:
+            traffic = {"hbm_bytes_per_launch": pmc["hbm_bytes_per_launch_corrected"],
+                       "source": f"profiles/{pmc['tag']}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, workload {wl_key}, "
+                                 f"kernel build {build_id})",
                        "correction": pmc["correction"]}
+            for k in ("mfma_busy_pct_serialised", "hbm_gbps_serialised", "avg_launch_us_rocprof", "flow"):
+                if k in pmc:
+                    pmc_extra[k] = pmc[k]
     except Exception:
         pass
     if rank == 0:
+        steps = max(1, args.steps)
         value = total_samples / elapsed
-        achieved_tf = (mfma_flops / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        mfma_ms, launches = acc.get("ms_decoder_mfma", 0.0), acc.get("decoder_mfma_launches", 0.0)
+        achieved_tf = (acc.get("flops_decoder_mfma", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        issued_tf = (acc.get("flops_decoder_mfma_executed", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        # per-stage rooflines of the part of the step that is NOT the matrix-core decoder: bound = max(bytes / HBM peak, flops / MFMA peak)
+        stages = {}
+        for name, kms, kfl, kby in (("text_encoder", "ms_text_encoder", "flops_text_encoder", "bytes_text_encoder"),
+                                    ("duration", "ms_duration", "flops_duration", "bytes_duration"),
+                                    ("flow", "ms_flow", "flops_flow", "bytes_flow"),
+                                    ("decoder", "ms_decoder", "flops_decoder", "bytes_decoder_min")):
+            ms = acc.get(kms, 0.0) / steps
+            fl = acc.get(kfl, 0.0) / steps
+            by = acc.get(kby, 0.0) / steps
+            t_hbm = by / (PEAK_HBM_GBS * 1e9) * 1e3
+            t_mfma = fl / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3
+            bound_ms = max(t_hbm, t_mfma)
+            stages[name] = {"ms": ms, "gflop": fl / 1e9, "mbytes": by / 1e6, "bound": "hbm" if t_hbm >= t_mfma else "mfma",
+                            "bound_ms": bound_ms, "frac_of_bound": (bound_ms / ms) if ms > 0 else None,
+                            "hbm_gbps_algorithmic": (by / 1e9) / (ms * 1e-3) if ms > 0 else None,
+                            "tflops_algorithmic": (fl / 1e12) / (ms * 1e-3) if ms > 0 else None}
         out = {
             "metric": "audio samples/sec (acoustic model + vocoder, phoneme ids -> int16 PCM on host), "
                       "single_speaker_fast-shaped synthetic blob",
@@ -237,21 +404,26 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / steps,
             "p50_latency_ms": 1e3 * float(np.median(lat)),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (seeded random weights in the reference .bin grammar; ids[i]=(i*37+11) mod vocab)",
+            "data": "synthetic (seeded random weights in the reference .bin grammar; ids[i]=(i*37+11) mod vocab); the reference's "
+                    "real .bin models are absent from /root/reference, every number here is on synthetic weights",
             "config": {
                 "workload": f"configs[1]: single_speaker_fast (synthetic '{args.workload}' blob, "
                             f"{blob.size} floats), batch={args.batch}/GPU, "
                             + ("64..256 phonemes/utterance (ragged)" if args.ragged else f"{args.phonemes} phonemes/utterance"),
                 "global_batch": gB, "phonemes": args.phonemes, "frames_per_step_rank0": int(last["frames"]),
                 "samples_per_step_rank0": int(last["samples"]), "parallelism": f"utterance-sharded x{world}",
+                "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("STS_BENCH_SELF_LAUNCHED") else
+                               ("torchrun / external launcher" if world > 1 else "single process"),
+                "kernel_build_id": build_id,
             },
-            "stage_ms_per_step": {k: float(v / args.steps) for k, v in zip(("text_encoder", "duration", "flow", "decoder"), stage_ms)},
+            "stage_ms_per_step": {k: stages[k]["ms"] for k in ("text_encoder", "duration", "flow", "decoder")},
+            "host_sync_wait_ms_per_step": acc.get("ms_sync_wait_host", 0.0) / steps,
             "roofline": {
                 "kernel": "conv_mfma_kernel + conv_mfma_group_kernel + resblock_wino_kernel / resblock_layer_kernel (decoder upsamplers + grouped / fused ResBlock convs, v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma",
@@ -260,26 +432,45 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": dec_bytes / max(1, launches),
-                "launches_per_step": launches / max(1, args.steps),
-                "avg_launch_us": 1e3 * mfma_ms / max(1, launches),
-                "flops_note": "achieved = ALGORITHMIC (direct-form, true-tap) FLOPs / time; the Winograd-domain layer kernels "
-                              "(resblock_wino_kernel) execute about 0.73x as many MFMA FLOPs for the same fp32 result",
-                "algorithmic_gflop_per_step": mfma_flops / max(1, args.steps) / 1e9,
-                "decoder_min_hbm_gb_per_step": dec_bytes / max(1, args.steps) / 1e9,
+                "achieved_definition": "ALGORITHMIC (direct-form, true-tap) FLOPs of the launches / their HIP-event time: the task's "
+                                       "roofline figure (SURVEY.md 8d).  It is an effective rate, not pipe utilisation -- see mfma_issued_*",
+                "mfma_issued_tflops": issued_tf,
+                "mfma_issued_frac": issued_tf / PEAK_F32_MFMA_TFLOPS,
+                "mfma_issued_definition": "matrix-core FLOPs the launches execute (the Winograd-domain layer kernels need (4 n3 + 3 n2) / (2 k) "
+                                          "of a k-tap conv's products) / the same time: <= 1 by construction",
+                "algorithmic_bytes_per_launch": acc.get("bytes_decoder_min", 0.0) / max(1.0, launches),
+                "launches_per_step": launches / steps,
+                "avg_launch_us": 1e3 * mfma_ms / max(1.0, launches),
+                "algorithmic_gflop_per_step": acc.get("flops_decoder_mfma", 0.0) / steps / 1e9,
+                "decoder_min_hbm_gb_per_step": acc.get("bytes_decoder_min", 0.0) / steps / 1e9,
             },
+            "roofline_stages": stages,
         }
+        out["roofline"].update(pmc_extra)
+        if dist is not None:
+            out["multi_gpu"] = {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
+                                "samples_per_rank": per_rank, "utterances_per_rank": [len(s_) for s_ in shards],
+                                "gather_busy_ms_per_step_rank0": 1e3 * gather_busy[0] / steps,
+                                "gather_drain_wait_ms_rank0": 1e3 * drain_wait,
+                                "gathered_samples_rank0": gathered[0],
+                                "note": "the gather of step k runs on a helper thread under step k + 1; gather_drain_wait is what was "
+                                        "left un-overlapped when the clock stopped"}
         if pipelined is not None:
             out["request_pool"] = pipelined
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stub:
             try:
-                out["cpu_baseline"] = cpu_baseline(blob, cfg, cfg.vocab, args.cpu_sample_phonemes)
+                cpu_T = args.cpu_sample_phonemes or (len(ids[0]) if ids else args.phonemes)
+                cpu_ids = ids[0] if (ids and cpu_T == len(ids[0])) else sb.synthetic_ids(cpu_T, cfg.vocab)
+                out["cpu_baseline"] = cpu_baseline(blob, cfg.vocab, cpu_ids, args.cpu_reps,
+                                                   [int(x) for x in args.cpu_threads.split(",") if x])
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": str(e)}
         result_line = json.dumps(out)
     else:
         result_line = None
     if dist is not None:
+        if gq is not None:
+            gq.put(None)
         dist.destroy_process_group()
     if result_line is not None:      # the JSON line is the LAST thing on stdout (RCCL may print banners earlier)
         sys.stdout.flush()

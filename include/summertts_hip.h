@@ -113,6 +113,10 @@ typedef struct sts_profile {
     double flops_decoder_mfma;      /* FLOPs executed by the launches timed in ms_decoder_mfma */
     double bytes_decoder_min;       /* algorithmic HBM bytes of the decoder (weights once + act in/out per conv) */
     int64_t frames, samples, phonemes;
+    double flops_decoder_mfma_executed;   /* matrix-core FLOPs the timed launches actually execute: the Winograd-domain layer
+                                             kernels need (4 n3 + 3 n2) / (2 k) of a k-tap conv's direct-form products */
+    double bytes_text_encoder, bytes_duration, bytes_flow;   /* algorithmic HBM bytes per stage (as bytes_decoder_min) */
+    float ms_sync_wait_host;        /* host time blocked on the frame-count download (the one data-dependent sync) */
 } sts_profile;
 int sts_set_profiling(sts_engine* e, int enable);
 int sts_get_profile(const sts_engine* e, sts_profile* p);
@@ -151,6 +155,24 @@ int64_t sts_pool_submit(sts_pool* p, const int32_t* ids, int32_t n, int32_t sid,
 int sts_pool_wait(sts_pool* p, int64_t ticket, int16_t** pcm_out, int32_t* n_out);
 int sts_pool_stats(sts_pool* p, int64_t* batches, int64_t* requests);
 const char* sts_pool_last_error(void);
+
+/* ---- multi-device batch (no reference counterpart).  One host process drives n_devices GPUs:
+ * one engine (weights replicated) and one worker thread per entry of `devices` (HIP device indices; an index may repeat,
+ * e.g. {0, 0} = two engines on one GPU).  sts_multi_infer_ids_batch shards the B utterances by utterance -- longest first,
+ * greedy, balanced by phoneme count, no exchange between devices -- runs every shard as one packed batch on its device
+ * concurrently, and returns the PCM in INPUT order: pcm_out[b] is malloc()'d per utterance (release with sts_free),
+ * n_out[b] = its sample count.  On any failure every output is released and a negative STS_E* code is returned.
+ * The handle is not re-entrant (one batch at a time), like an engine. */
+typedef struct sts_multi sts_multi;
+int sts_multi_create(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, sts_multi** out);
+void sts_multi_destroy(sts_multi* m);
+int sts_multi_device_count(const sts_multi* m);
+int sts_multi_speaker_num(const sts_multi* m);
+int sts_multi_infer_ids_batch(sts_multi* m, int32_t B, const int32_t* const* ids, const int32_t* n, const int32_t* sid,
+                              const float* length_scale, int16_t** pcm_out, int32_t* n_out);
+/* the placement sts_multi_infer_ids_batch would use: device_slot_out[b] = index into `devices` (host logic only) */
+int sts_multi_shard_of(const sts_multi* m, int32_t B, const int32_t* n, int32_t* device_slot_out);
+const char* sts_multi_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,11 @@ int sts_infer_ids_batch(sts_engine* e, int32_t B, const int32_t* const* ids, con
     for (int b = 0; b < B; b++) {
         if (B == 1) { pcm_out[0] = all; break; }   // single utterance: hand over the buffer itself
         pcm_out[b] = (int16_t*)malloc((size_t)(n_out[b] > 0 ? n_out[b] : 1) * 2);
-        if (!pcm_out[b]) { free(all); return set_err(STS_EDEVICE, "out of host memory"); }
+        if (!pcm_out[b]) {
+            for (int q = 0; q < b; q++) { free(pcm_out[q]); pcm_out[q] = nullptr; }
+            free(all);
+            return set_err(STS_EDEVICE, "out of host memory");
+        }
         memcpy(pcm_out[b], all + off, (size_t)n_out[b] * 2);
         off += n_out[b];
     }

@@ -88,7 +88,7 @@ __device__ __forceinline__ void epi_scalar(const ConvArgs& a, int row, size_t op
         case EPI_TANH_PCM: {
             float t = tanh_ref(v);
             if (a.aux) a.aux[opos] = t;
-            a.pcm[opos] = (int16_t)(int32_t)(t * 32737.0f);
+            a.pcm[opos] = pcm_cast(t);
             break;
         }
         default: break;

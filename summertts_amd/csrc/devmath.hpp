@@ -4,6 +4,7 @@
 // (never the fast __expf approximations).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 namespace sts {
 
@@ -25,5 +26,15 @@ __device__ __forceinline__ float gelu_ref(float x) {
 }
 // /root/reference/src/nn_op/nn_softplus.cpp:3-8: log(e^x + 1), no threshold
 __device__ __forceinline__ float softplus_ref(float x) { return logf(expf(x) + 1.0f); }
+
+// /root/reference/src/models/SynthesizerTrn.cpp:393-396: (int16_t)(o * 32737) -- no clip.  The reference build (x86-64,
+// gcc) converts with cvttss2si to a 32-bit integer and keeps the low 16 bits: in-range values truncate toward zero,
+// |v| < 2^31 wraps around modulo 2^16, anything beyond (and NaN) becomes 0x80000000 -> 0.  v_cvt_i32_f32 saturates
+// instead, so the out-of-int32 case is mapped explicitly.
+__device__ __forceinline__ int16_t pcm_cast(float o) {
+    const float v = o * 32737.0f;
+    const int32_t q = fabsf(v) < 2147483648.0f ? (int32_t)v : (int32_t)0x80000000;
+    return (int16_t)q;
+}
 
 }  // namespace sts

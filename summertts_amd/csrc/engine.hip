@@ -7,6 +7,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -110,10 +111,11 @@ ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float
     const double positions = c.transposed ? (double)lin.total : (double)lout.total;
     const double fl = 2.0 * c.macs_per_out * positions;
     flops_[cur_stage_] += fl;
-    if (cur_stage_ == 3) {
+    {   // algorithmic HBM bytes: input once, output once, weights once (+ residual / read-modify-write operands)
         const size_t wfl = c.depthwise ? (size_t)c.k * c.Cout : (size_t)c.k * c.Cin * c.Cout;
-        dec_bytes_ += 4.0 * ((double)c.Cin * lin.total + (double)c.Cout * lout.total + (double)wfl);
-        if (o.res) dec_bytes_ += 4.0 * (double)c.Cout * lout.total;
+        double by = 4.0 * ((double)c.Cin * lin.total + (double)c.Cout * lout.total + (double)wfl);
+        if (o.res || o.epi == EPI_SUB || o.epi == EPI_RESSKIP) by += 4.0 * (double)c.Cout * lout.total;
+        bytes_[cur_stage_] += by;
     }
     if (flops) *flops = fl;
     return a;
@@ -124,7 +126,7 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     const ConvArgs a = conv_args(c, x, lin, y, lout, o, &fl);
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
     if (can_mfma) {
-        if (in_mfma_region_) { mfma_flops_ += fl; mfma_launches_++; }
+        if (in_mfma_region_) { mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_++; }
         conv_mfma(a, cur_, conv_mode >= 2 ? conv_mode - 2 : -1);
     } else {
         conv_generic(a, cur_);
@@ -137,6 +139,7 @@ void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, 
     g.a = a; g.a_ld = lv.ld; g.b = b; g.b_ld = lv.ld; g.res = res; g.res_ld = lv.ld; g.y = y; g.y_ld = lv.ld;
     g.gamma = l.g; g.beta = l.b; g.C = l.C; g.pre_relu = pre_relu; g.post_gelu = post_gelu;
     g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
+    bytes_[cur_stage_] += 4.0 * (double)l.C * (double)lv.total * (2.0 + (b ? 1.0 : 0.0) + (res ? 1.0 : 0.0));
     layer_norm(g, cur_);
 }
 
@@ -152,6 +155,7 @@ void Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv) {
             g.dw_w = c.w; g.dw_b = c.bias; g.dw_k = c.k; g.dw_dil = c.dil; g.dw_pad = c.pad; g.dw_ld = c.Cout_pad;
             g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
             flops_[cur_stage_] += 2.0 * c.macs_per_out * (double)lv.total;
+            bytes_[cur_stage_] += 4.0 * (double)g.C * (double)lv.total * 2.0;
             layer_norm(g, cur_);
         }
         conv(d.pw[i], t1, lv, t2, lv, ConvOpt());
@@ -211,7 +215,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     taps.clear();
     memset(&prof, 0, sizeof(prof));
     for (double& f : flops_) f = 0;
-    mfma_flops_ = 0; dec_bytes_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+    for (double& f : bytes_) f = 0;
+    mfma_flops_ = 0; mfma_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
 
     // ---------------- host-side batch geometry (phoneme level)
     std::vector<int> offT(B), lenT(B);
@@ -297,6 +302,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         at.seg = lvT.seg; at.B = B; at.max_len = maxT;
         attention(at, stream);
         flops_[0] += 2.0 * 2.0 * (double)a.ch * (double)maxT * (double)Ttot;   // ~ QK^T + PV
+        bytes_[0] += 4.0 * 4.0 * (double)H * (double)Ttot;                       // q, k, v in; o out
         conv(a.o, bt.att, lvT, bt.y, lvT, ConvOpt());
         ln(M.ln1[l], bt.x, bt.y, nullptr, bt.x1, lvT, 0, 0);
         const DFfn& f = M.ffn[l];
@@ -361,7 +367,11 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     // ---------------- the one data-dependent sync: frame counts (+ durations for the API)
     int* p_down = (int*)(pinned_ + up_bytes);
     HIPCK(hipMemcpyAsync(p_down, bt.dur, ((size_t)Ttot + B) * 4, hipMemcpyDeviceToHost, stream));
-    HIPCK(hipStreamSynchronize(stream));
+    {
+        const auto w0 = std::chrono::steady_clock::now();
+        HIPCK(hipStreamSynchronize(stream));
+        sync_wait_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
     durations_h.assign(p_down, p_down + Ttot);
     tap("logw", bt.dlogw, 1, Ttot, Ttot);
     long Ftot = 0; int maxF = 0;
@@ -480,9 +490,9 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         for (int j = 0; j < nk && grouped; j++) grouped = (int)M.rb[(size_t)i * nk + j].c1.size() == nd0;
         if (grouped) {   // probe with layer 0 (geometry is the same for every layer of a chain)
             ConvGroup G; G.n = nk;
-            const double f0 = flops_[3], b0 = dec_bytes_;
+            const double f0 = flops_[3], b0 = bytes_[3];
             for (int j = 0; j < nk; j++) G.g[j] = conv_args(M.rb[(size_t)i * nk + j].c1[0], bup, l2, bup, l2, ConvOpt(), nullptr);
-            flops_[3] = f0; dec_bytes_ = b0;
+            flops_[3] = f0; bytes_[3] = b0;
             grouped = conv_group_eligible(G);
         }
         if (grouped) {
@@ -514,21 +524,23 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 // the 128-channel variant runs 8-wave workgroups, two per CU: only worth it when the grid fills the chip twice
                 if (fuse && R.C > 64) fuse = (long)((l2.max_len + 117) / 118) * l2.nb * nk >= 512;
                 if (fuse && resblock_layer_eligible(R)) {
-                    double fl = 0, f = 0;
+                    double fl = 0, flw = 0, f = 0;
+                    auto wino_ratio = [](int k) { int n3, n2; wino_split(k, &n3, &n2); return (4.0 * n3 + 3.0 * n2) / (2.0 * k); };
                     for (int j = 0; j < nk; j++) {   // book FLOPs / algorithmic bytes exactly as for the two separate convs
                         const DResBlock& rb = M.rb[(size_t)i * nk + j];
                         ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
-                        (void)conv_args(rb.c1[d], cur[j], l2, R.g[j].y, l2, o1, &f); fl += f;
+                        (void)conv_args(rb.c1[d], cur[j], l2, R.g[j].y, l2, o1, &f); fl += f; flw += f * wino_ratio(rb.c1[d].k);
                         ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur[j]; o2.epi = EPI_RESADD;
-                        (void)conv_args(rb.c2[d], cur[j], l2, R.g[j].y, l2, o2, &f); fl += f;
+                        (void)conv_args(rb.c2[d], cur[j], l2, R.g[j].y, l2, o2, &f); fl += f; flw += f * wino_ratio(rb.c2[d].k);
                         cur[j] = R.g[j].y;
                     }
                     // both convs in the Winograd domain when the model carries the transformed weights (-31 % MFMAs);
                     // the direct-form fused kernel otherwise
                     static const bool no_wino = getenv("STS_NO_WINO") != nullptr;   // experiment knob
-                    if (!no_wino && resblock_wino_eligible(R)) resblock_wino(R, stream);
+                    const bool wino = !no_wino && resblock_wino_eligible(R);
+                    if (wino) resblock_wino(R, stream);
                     else resblock_layer(R, stream);
-                    mfma_flops_ += fl; mfma_launches_ += 1;
+                    mfma_flops_ += fl; mfma_exec_ += wino ? flw : fl; mfma_launches_ += 1;
                     continue;
                 }
                 ConvGroup G1, G2; G1.n = G2.n = nk;
@@ -545,9 +557,13 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 }
                 static const char* gt = getenv("STS_GROUP_TILE");   // experiment knob: per-stage tile digits, e.g. "4335"
                 const int gtile = gt && (int)strlen(gt) > i ? gt[i] - '0' : -1;
-                conv_mfma_group(G1, stream, gtile);
-                conv_mfma_group(G2, stream, gtile);
-                mfma_flops_ += fl1 + fl2; mfma_launches_ += 2;
+                // every layer is checked on its own: later layers have larger dilations, and a halo beyond the staged
+                // LDS window (e.g. k = 11 with dilation 7) must take the per-conv path, which falls back to conv_generic
+                if (conv_group_eligible(G1)) conv_mfma_group(G1, stream, gtile);
+                else for (int j = 0; j < nk; j++) { if (conv_mfma_eligible(G1.g[j])) conv_mfma(G1.g[j], stream, -1); else conv_generic(G1.g[j], stream); }
+                if (conv_group_eligible(G2)) conv_mfma_group(G2, stream, gtile);
+                else for (int j = 0; j < nk; j++) { if (conv_mfma_eligible(G2.g[j])) conv_mfma(G2.g[j], stream, -1); else conv_generic(G2.g[j], stream); }
+                mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
             }
             for (int j = 0; j < nk; j++) outs[j] = cur[j];
         } else {
@@ -664,7 +680,10 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
 
     prof.frames = Ftot; prof.samples = Ntot; prof.phonemes = Ttot;
     prof.flops_text_encoder = flops_[0]; prof.flops_duration = flops_[1]; prof.flops_flow = flops_[2]; prof.flops_decoder = flops_[3];
-    prof.flops_decoder_mfma = mfma_flops_; prof.decoder_mfma_launches = mfma_launches_; prof.bytes_decoder_min = dec_bytes_ + 2.0 * (double)Ntot;
+    prof.flops_decoder_mfma = mfma_flops_; prof.decoder_mfma_launches = mfma_launches_; prof.bytes_decoder_min = bytes_[3] + 2.0 * (double)Ntot;
+    prof.flops_decoder_mfma_executed = mfma_exec_;
+    prof.bytes_text_encoder = bytes_[0]; prof.bytes_duration = bytes_[1]; prof.bytes_flow = bytes_[2];
+    prof.ms_sync_wait_host = (float)sync_wait_ms_;
     if (profiling) {
         float t = 0;
         (void)hipEventElapsedTime(&t, ev_[0], ev_[1]); prof.ms_text_encoder = t;

@@ -90,7 +90,8 @@ private:
     bool have_events_ = false;
     int cur_stage_ = 0;
     double flops_[4] = {0, 0, 0, 0};
-    double mfma_flops_ = 0, dec_bytes_ = 0; int mfma_launches_ = 0; bool in_mfma_region_ = false;
+    double bytes_[4] = {0, 0, 0, 0};
+    double mfma_flops_ = 0, mfma_exec_ = 0, sync_wait_ms_ = 0; int mfma_launches_ = 0; bool in_mfma_region_ = false;
 };
 
 }  // namespace sts

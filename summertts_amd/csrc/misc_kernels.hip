@@ -146,14 +146,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     for (int c = tid; c < kc; c += 256) qs[c] = a.q[(size_t)(h * kc + c) * a.ld + base + i] / sq;
     __syncthreads();
     // banded relative-key logits q . relK[r], r = 0..px-1: one 16-lane group per r, shuffle-reduced
-    float* qrel = part + 4 * T;      // [16]
-    if (a.win > 0 && tid < 16 * a.px && tid < 256) {
-        const int r = tid >> 4, l16 = tid & 15;
-        float s = 0.f;
-        for (int c = l16; c < kc; c += 16) s += qs[c] * a.relk[(size_t)c * a.px + r];
+    float* qrel = part + 4 * T;      // [px]
+    if (a.win > 0) {
+        const int l16 = tid & 15;
+        for (int r = tid >> 4; r < a.px; r += 16) {   // 16 groups of 16 lanes; any window size (px = 2 win + 1)
+            float s = 0.f;
+            for (int c = l16; c < kc; c += 16) s += qs[c] * a.relk[(size_t)c * a.px + r];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-        if (l16 == 0) qrel[r] = s;
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+            if (l16 == 0) qrel[r] = s;
+        }
     }
     // wave w owns channels [c0, c1)
     const int cw = (kc + 3) / 4, c0 = wave * cw, c1 = c0 + cw < kc ? c0 + cw : kc;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 }
 void attention(const AttnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
-    size_t lds = (size_t)(a.kc + 8 + 16 + 5 * (size_t)a.max_len) * sizeof(float);
+    size_t lds = (size_t)(a.kc + 8 + (a.px > 16 ? a.px : 16) + 5 * (size_t)a.max_len) * sizeof(float);
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attention_kernel, dim3(a.max_len, a.nheads, a.B), dim3(256), lds, st, a);
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void synth_fir_kernel(const float* tm, long tm
         for (int q = 0; q < 4; q++) s += (gain * tm[(size_t)q * tm_ld + tb + t]) * fir[tau * 4 + q];
     }
     if (wave) wave[ob + i] = s;
-    pcm[ob + i] = (int16_t)(int32_t)(s * 32737.0f);
+    pcm[ob + i] = pcm_cast(s);
 }
 void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, int ntap, int pad, float gain, float* wave,
                int16_t* pcm, SegView seg_out, int B, int max_n, hipStream_t st) {
@@ -541,7 +543,7 @@ void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, in
 
 __global__ void quantize_pcm_kernel(const float* wave, int16_t* pcm, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) pcm[i] = (int16_t)(int32_t)(wave[i] * 32737.0f);
+    if (i < n) pcm[i] = pcm_cast(wave[i]);
 }
 void quantize_pcm(const float* wave, int16_t* pcm, long n, hipStream_t st) {
     if (n <= 0) return;

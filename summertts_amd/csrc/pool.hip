@@ -27,7 +27,7 @@ struct Request {
     int64_t ticket = 0;
     std::vector<int32_t> ids; int32_t sid = 0; float ls = 1.f;
     // result
-    bool done = false; int rc = STS_OK; std::string err;
+    bool done = false, waited = false; int rc = STS_OK; std::string err;
     int16_t* pcm = nullptr; int32_t n = 0;
 };
 }  // namespace
@@ -152,8 +152,10 @@ int sts_pool_wait(sts_pool* p, int64_t ticket, int16_t** pcm_out, int32_t* n_out
         auto it = p->pending.find(ticket);
         if (it == p->pending.end()) return pool_err(STS_EINVAL, "unknown ticket");
         r = it->second;
-        p->cv_done.wait(lk, [&] { return r->done; });
-        p->pending.erase(it);
+        if (r->waited) return pool_err(STS_EINVAL, "ticket is already being waited on");
+        r->waited = true;
+        p->cv_done.wait(lk, [&] { return r->done; });   // releases the mutex: `it` may be stale afterwards
+        p->pending.erase(ticket);
     }
     if (r->rc != STS_OK) { if (r->pcm) free(r->pcm); return pool_err(r->rc, r->err); }
     *pcm_out = r->pcm; *n_out = r->n;

@@ -36,7 +36,9 @@ class Profile(C.Structure):
                 ("decoder_mfma_launches", C.c_int32), ("flops_text_encoder", C.c_double),
                 ("flops_duration", C.c_double), ("flops_flow", C.c_double), ("flops_decoder", C.c_double),
                 ("flops_decoder_mfma", C.c_double), ("bytes_decoder_min", C.c_double), ("frames", C.c_int64),
-                ("samples", C.c_int64), ("phonemes", C.c_int64)]
+                ("samples", C.c_int64), ("phonemes", C.c_int64), ("flops_decoder_mfma_executed", C.c_double),
+                ("bytes_text_encoder", C.c_double), ("bytes_duration", C.c_double), ("bytes_flow", C.c_double),
+                ("ms_sync_wait_host", C.c_float)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -89,6 +91,8 @@ EXPORTED_SYMBOLS = [
     "sts_get_profile", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
     "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
+    "sts_multi_create", "sts_multi_destroy", "sts_multi_device_count", "sts_multi_speaker_num", "sts_multi_infer_ids_batch",
+    "sts_multi_shard_of", "sts_multi_last_error",
 ]
 
 
@@ -305,6 +309,68 @@ class Pool:
     def close(self):
         if self.h:
             self.lib.sts_pool_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiDevice:
+    """``sts_multi``: one process, one engine per listed HIP device; batches are sharded by utterance."""
+
+    def __init__(self, blob: np.ndarray, devices: Sequence[int]):
+        self.lib = load_library()
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self.h = C.c_void_p()
+        self.lib.sts_multi_last_error.restype = C.c_char_p
+        self.lib.sts_multi_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        self.lib.sts_multi_destroy.argtypes = [C.c_void_p]
+        self.lib.sts_multi_device_count.argtypes = [C.c_void_p]
+        self.lib.sts_multi_speaker_num.argtypes = [C.c_void_p]
+        self.lib.sts_multi_infer_ids_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_void_p, C.c_void_p]
+        self.lib.sts_multi_shard_of.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        rc = self.lib.sts_multi_create(blob.ctypes.data, blob.nbytes, dev.ctypes.data, dev.size, C.byref(self.h))
+        if rc != 0:
+            raise StsError(f"sts_multi_create: {rc}: {self.lib.sts_multi_last_error().decode()}")
+
+    def device_count(self) -> int:
+        return int(self.lib.sts_multi_device_count(self.h))
+
+    def shard_of(self, lengths: Sequence[int]) -> np.ndarray:
+        n = np.ascontiguousarray(lengths, dtype=np.int32)
+        out = np.zeros(n.size, np.int32)
+        rc = self.lib.sts_multi_shard_of(self.h, n.size, n.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise StsError(f"sts_multi_shard_of: {rc}: {self.lib.sts_multi_last_error().decode()}")
+        return out
+
+    def infer_batch(self, ids, sid=None, length_scale=None) -> List[np.ndarray]:
+        B = len(ids)
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in ids]
+        ptrs = (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
+        n = np.asarray([a.size for a in arrs], dtype=np.int32)
+        sidv = np.zeros(B, np.int32) if sid is None else np.ascontiguousarray(sid, dtype=np.int32)
+        lsv = np.ones(B, np.float32) if length_scale is None else np.ascontiguousarray(length_scale, dtype=np.float32)
+        outp = (C.POINTER(C.c_int16) * B)()
+        n_out = np.zeros(B, np.int32)
+        rc = self.lib.sts_multi_infer_ids_batch(self.h, B, ptrs, n.ctypes.data, sidv.ctypes.data, lsv.ctypes.data,
+                                                C.cast(outp, C.c_void_p), n_out.ctypes.data)
+        if rc != 0:
+            raise StsError(f"sts_multi_infer_ids_batch: {rc}: {self.lib.sts_multi_last_error().decode()}")
+        res = []
+        for b in range(B):
+            res.append(np.ctypeslib.as_array(outp[b], shape=(int(n_out[b]),)).copy() if n_out[b] else np.zeros(0, np.int16))
+            self.lib.sts_free(C.cast(outp[b], C.c_void_p))
+        return res
+
+    def close(self):
+        if self.h:
+            self.lib.sts_multi_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -32,14 +32,25 @@ class PendingGather:
     __slots__ = ("work", "big", "buf", "cnts", "rank", "world")
 
 
-def begin_gather(local, counts_local, dist, torch, rank: int, world: int, max_utts: int) -> PendingGather:
+def begin_gather(local, counts_local, dist, torch, rank: int, world: int, max_utts: int = 0) -> PendingGather:
     """Starts the gather of one variable-length int16 tensor per rank to rank 0 and returns at once.
 
-    local: 1-D int16 tensor (on the backend's device) holding this rank's utterances back to back;
+    local: 1-D int16 tensor (on the backend's device) holding this rank's utterances back to back (empty for a rank
+    whose shard is empty -- it still takes part in both collectives);
     counts_local: per-utterance sample counts (python ints).  The sample counts are exchanged first (one tiny
     all_gather + one download: the payload buffers are sized from them); the PCM itself travels asynchronously
-    (``async_op``) so that the caller can start the next batch while RCCL moves it."""
+    (``async_op``) so that the caller can start the next batch while RCCL moves it.
+    max_utts: the largest shard size over ALL ranks (shards differ in size: ``shard_utterances([5, 5, 5], 4)`` leaves
+    rank 3 empty).  0 = agree on it here with one all_reduce(MAX), so ranks can never build count tensors of
+    different lengths."""
     dev = local.device
+    if max_utts <= 0:
+        mx = torch.tensor([len(counts_local)], dtype=torch.int64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        max_utts = int(mx.item())
+    max_utts = max(1, max_utts)
+    if len(counts_local) > max_utts:
+        raise ValueError(f"shard of {len(counts_local)} utterances exceeds max_utts={max_utts}")
     cnt_h = np.zeros(max_utts + 1, dtype=np.int64)
     cnt_h[0] = len(counts_local)
     cnt_h[1:1 + len(counts_local)] = list(counts_local)
@@ -76,25 +87,36 @@ def finish_gather(h: PendingGather):
     return out
 
 
-def gather_variable(local, counts_local, dist, torch, rank: int, world: int, max_utts: int):
+def gather_variable(local, counts_local, dist, torch, rank: int, world: int, max_utts: int = 0):
     """Blocking form: begin_gather + finish_gather."""
     return finish_gather(begin_gather(local, counts_local, dist, torch, rank, world, max_utts))
 
 
-def gather_pcm(syn, n_out, dist, torch, rank: int, world: int, max_utts: int = 0):
-    """Device-side PCM of the last ``syn.run_batch`` -> rank 0 (RCCL).  Returns (per-rank lists, counts)."""
-    total = int(np.asarray(n_out).sum())
+def _local_pcm(syn, n_out, torch):
+    """This rank's PCM of the last ``syn.run_batch`` as a device tensor (empty shard: no run happened, nothing to copy)."""
+    total = int(np.asarray(n_out).sum()) if len(n_out) else 0
     local = torch.empty(max(1, total), dtype=torch.int16, device="cuda")
-    syn.pcm_to_device_ptr(local.data_ptr(), local.numel())
-    res = gather_variable(local[:total], [int(v) for v in n_out], dist, torch, rank, world,
-                          max_utts or max(1, len(n_out)))
+    if len(n_out):
+        syn.pcm_to_device_ptr(local.data_ptr(), local.numel())
+    return local[:total]
+
+
+def run_shard(syn, ids, sid, length_scale):
+    """``syn.run_batch`` that tolerates an empty shard (a rank with no utterances skips the engine but must still
+    join the gather collectives)."""
+    if len(ids) == 0:
+        return np.zeros(0, np.int32)
+    return syn.run_batch(ids, sid, length_scale)
+
+
+def gather_pcm(syn, n_out, dist, torch, rank: int, world: int, max_utts: int = 0):
+    """Device-side PCM of the last ``syn.run_batch`` -> rank 0 (RCCL).  Returns (per-rank lists, counts).
+    max_utts = 0: agreed on with an all_reduce(MAX) inside begin_gather."""
+    res = gather_variable(_local_pcm(syn, n_out, torch), [int(v) for v in n_out], dist, torch, rank, world, max_utts)
     return res, n_out
 
 
 def begin_gather_pcm(syn, n_out, dist, torch, rank: int, world: int, max_utts: int = 0) -> PendingGather:
     """Asynchronous form of gather_pcm: the engine's PCM is copied out (device to device) and handed to RCCL;
     the engine is free for the next batch as soon as this returns."""
-    total = int(np.asarray(n_out).sum())
-    local = torch.empty(max(1, total), dtype=torch.int16, device="cuda")
-    syn.pcm_to_device_ptr(local.data_ptr(), local.numel())
-    return begin_gather(local[:total], [int(v) for v in n_out], dist, torch, rank, world, max_utts or max(1, len(n_out)))
+    return begin_gather(_local_pcm(syn, n_out, torch), [int(v) for v in n_out], dist, torch, rank, world, max_utts)

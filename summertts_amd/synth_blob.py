@@ -85,6 +85,13 @@ class ModelCfg:
     gin: int = 0
     # synthetic-duration control: logw ~= dur_bias (+- small)
     dur_bias: float = 1.55
+    # output-amplitude controls (defaults keep |o| ~ 0.05-0.2; the amplitude-edge tests raise them):
+    # gain of the HiFi-GAN conv_post weights (tanh saturation) / of the iSTFT heads, and the bias added to the
+    # log-magnitude rows of the MB-iSTFT heads (|X_k| ~ e^mag_bias: > 0 drives |o| past 1.0 -> int16 wrap-around)
+    post_gain: float = 0.35
+    head_gain: float = 0.25
+    mag_bias: float = -1.0
+    istft_mag_bias: float = 0.0
 
     @property
     def hop_total(self) -> int:
@@ -104,6 +111,8 @@ def full_cfg(kind: str) -> ModelCfg:
         return ModelCfg(dur_type=DUR_FIX, dec_type=DEC_MBB, up_rates=(4, 4), up_k=(16, 16))
     if kind == "ms_fix":                # MS-iSTFT-VITS (learned synthesis filter)
         return ModelCfg(dur_type=DUR_FIX, dec_type=DEC_MS, up_rates=(4, 4), up_k=(16, 16))
+    if kind == "ms_sdp":                # MS-iSTFT-VITS decoder + stochastic duration predictor
+        return ModelCfg(dec_type=DEC_MS, up_rates=(4, 4), up_k=(16, 16), dur_bias=1.0)   # ~5.4 frames per phoneme
     if kind == "istft_fix":
         return ModelCfg(dur_type=DUR_FIX, dec_type=DEC_ISTFT, up_rates=(8, 8), up_k=(16, 16))
     if kind == "ms_hifigan_sdp":        # multi-speaker (aishell3-like)
@@ -255,7 +264,7 @@ def _decoder(w: _W, cfg: ModelCfg):
     if cfg.dec_type == DEC_HIFIGAN:
         _gen_hdr(w, cfg)
         ch = _gen_body(w, cfg)
-        _conv1d(w, 1, ch, 7, pad=3, bias=False, gain=0.35)
+        _conv1d(w, 1, ch, 7, pad=3, bias=False, gain=cfg.post_gain)
         if cfg.is_ms:
             _conv1d(w, cfg.up_init, cfg.gin, 1, gain=0.3)
         return
@@ -264,15 +273,20 @@ def _decoder(w: _W, cfg: ModelCfg):
     ch = _gen_body(w, cfg)
     nbin = cfg.nfft // 2 + 1
     if cfg.dec_type == DEC_ISTFT:
-        _conv1d(w, 2 * nbin, ch, 7, pad=3, gain=0.25, bias_std=0.01)
+        # same stream as _conv1d(w, 2 * nbin, ch, 7, pad=3, gain=head_gain, bias_std=0.01), plus the log-magnitude shift
+        w.ints(2 * nbin, ch, 7, 3, 1, 1)
+        w.arr(w.normal((2 * nbin, 7, ch), cfg.head_gain / np.sqrt(ch * 7)))
+        bs = w.normal((2 * nbin,), 0.01)
+        bs[:nbin] += np.float32(cfg.istft_mag_bias)
+        w.arr(bs)
         return
     # log-magnitude / phase heads; small so exp() stays O(1) and the waveform inside (-1,1)
     out = cfg.subbands * 2 * nbin
     w.ints(out, ch, 7, 3, 1, 1)
-    wt = w.normal((out, 7, ch), 0.25 / np.sqrt(ch * 7))
+    wt = w.normal((out, 7, ch), cfg.head_gain / np.sqrt(ch * 7))
     bs = w.normal((out,), 0.01)
     for b in range(cfg.subbands):       # push log-magnitudes down: |X_k| ~ e^-1
-        bs[b * 2 * nbin: b * 2 * nbin + nbin] -= 1.0
+        bs[b * 2 * nbin: b * 2 * nbin + nbin] += np.float32(cfg.mag_bias)
     w.arr(wt)
     w.arr(bs)
     if cfg.dec_type == DEC_MS:

@@ -3,7 +3,8 @@ and against the real reference itself where oracle/_ref exists; the blob grammar
 import numpy as np
 import pytest
 
-from conftest import (TAP_MAXABS_TOL, assert_pcm_close, assert_wave_close, golden_files, load_golden)
+from conftest import (TAP_MAXABS_TOL, AMP_WAVE_MAXABS_TOL, AMP_WAVE_RMSE_TOL, assert_pcm_close, assert_pcm_close_wrapped, assert_wave_close, golden_files,
+                      golden_files_v2, load_golden, load_golden_v2)
 from oracle import pyref
 from summertts_amd import synth_blob as sb
 
@@ -73,3 +74,35 @@ def test_pcm_quantisation_rule(port_built):
     o = pyref.PortModel(sb.make_blob(cfg, 3)).infer_ids(sb.synthetic_ids(6, cfg.vocab), 0, 1.0)
     expect = np.trunc(o["wave"].astype(np.float32) * np.float32(32737)).astype(np.int64)
     assert (o["pcm"].astype(np.int64) == expect).all()
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files_v2("amp_") if "full" not in p], ids=lambda p: p.split("/")[-1])
+def test_port_matches_reference_at_the_amplitude_edge(path, port_built):
+    """The restatement against the real reference's outputs at tanh saturation and beyond +-1.0 (int16 wrap-around of the
+    unclipped cast, SynthesizerTrn.cpp:393-396)."""
+    g, cfg, blob, utts, stride = load_golden_v2(path)
+    port = pyref.PortModel(blob)
+    for u, ids, sid, ls, dur, pcm, wave in utts:
+        o = port.infer_ids(ids, sid, ls)
+        assert (o["durations"] == dur).all()
+        peak = max(1.0, float(np.abs(wave).max()))
+        assert np.abs(o["wave"][::stride].astype(np.float64) - wave).max() <= AMP_WAVE_MAXABS_TOL * peak
+        assert_pcm_close_wrapped(o["pcm"], pcm, path)
+
+
+def test_full_size_golden_fixtures_are_well_formed():
+    """The full-size fixtures are too slow for the restatement on a CPU-only box; check what can be checked without
+    running a model: recipe hash, batch definition, PCM == trunc(wave * 32737) on the stored (strided) samples."""
+    paths = golden_files_v2("full_")
+    assert len(paths) >= 6
+    for path in paths:
+        g = np.load(path)
+        assert str(g["size"]) == "full" and int(g["wave_stride"]) == 8
+        for u in g["utts"]:
+            pcm, wave, dur = g[f"pcm_{u}"], g[f"wave_{u}"], g[f"dur_{u}"]
+            assert pcm.size % int(dur.sum()) == 0 and pcm.size // int(dur.sum()) == 256
+            expect = np.trunc(wave.astype(np.float32) * np.float32(32737)).astype(np.int64)
+            assert (pcm[::8].astype(np.int64) == expect).all()
+            assert g[f"ids_{u}"].size >= 64
+        if "batch_lens" in g:
+            assert len(g["batch_lens"]) == 8 and 64 <= min(g["batch_lens"]) and max(g["batch_lens"]) <= 256

@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from conftest import (TAP_MAXABS_TOL, assert_pcm_close, assert_wave_close, golden_files, load_golden)
+from conftest import (TAP_MAXABS_TOL, AMP_WAVE_MAXABS_TOL, AMP_WAVE_RMSE_TOL, assert_pcm_close, assert_pcm_close_wrapped, assert_wave_close,
+                      golden_files, golden_files_v2, load_golden, load_golden_v2)
 from oracle import pyref
 from summertts_amd import engine, synth_blob as sb
 
@@ -342,4 +343,130 @@ def test_realistic_size_against_the_real_reference():
     assert int(o["durations"].sum()) >= 330          # large enough for the 128-channel fused kernel (>= 512 workgroups)
     assert_wave_close(syn.tap("wave")[0], o["wave"], "realistic size vs reference")
     assert_pcm_close(syn.pcm_host(), o["pcm"], "realistic size vs reference")
+    syn.close()
+
+
+@pytest.mark.parametrize("path", golden_files_v2("full_"), ids=lambda p: p.split("/")[-1])
+def test_full_size_configs_match_reference_golden(path):
+    """BASELINE configs[2]-[4] at FULL model size against outputs of the real reference (tools/make_golden_full.py ran it):
+    MB-iSTFT (PQMF) and MS-iSTFT decoders at 96 phonemes (the grouped / fused / Winograd kernels engage), the multi-speaker
+    HiFi-GAN model (gin 256: cond paths of the duration predictor, the flow's WaveNet and the decoder) with three speaker
+    ids, and ragged 8-utterance batches (64..256 phonemes, the tile choices of a batched launch) of which two members
+    each carry reference outputs.  Durations equal, PCM within 1 LSB, float waveform within the stated tolerance."""
+    g, cfg, blob, utts, stride = load_golden_v2(path)
+    syn = engine.Synthesizer(blob)
+    assert syn.info.blob_floats_consumed == blob.size
+    syn.set_record_taps(True)
+    if "batch_lens" in g:
+        lens = [int(t) for t in g["batch_lens"]]
+        sids = [int(v) for v in g["batch_sids"]]
+        ids = [sb.synthetic_ids(t, cfg.vocab, salt=u) for u, t in enumerate(lens)]
+        n_out = syn.run_batch(ids, sids, [1.0] * len(ids))
+        pcm = syn.pcm_host()
+        wave = syn.tap("wave")[0]
+        dur = syn.durations(sum(lens))
+        soff = np.concatenate([[0], np.cumsum(n_out)])
+        toff = np.concatenate([[0], np.cumsum(lens)])
+        for u, ids_u, sid_u, ls_u, dur_u, pcm_u, wave_u in utts:
+            assert np.array_equal(ids_u, ids[u]) and sid_u == sids[u]
+            assert (dur[toff[u]:toff[u + 1]] == dur_u).all(), f"utterance {u}: durations differ from the reference"
+            assert_pcm_close(pcm[soff[u]:soff[u + 1]], pcm_u, f"{path} utterance {u} of the batch")
+            assert_wave_close(wave[soff[u]:soff[u + 1]][::stride], wave_u, f"{path} utterance {u} of the batch")
+    else:
+        for u, ids_u, sid_u, ls_u, dur_u, pcm_u, wave_u in utts:
+            syn.run_batch([ids_u], [sid_u], [ls_u])
+            assert (syn.durations(len(ids_u)) == dur_u).all(), f"utterance {u}: durations differ from the reference"
+            assert_pcm_close(syn.pcm_host(), pcm_u, f"{path} utterance {u}")
+            assert_wave_close(syn.tap("wave")[0][::stride], wave_u, f"{path} utterance {u}")
+    syn.close()
+
+
+@pytest.mark.parametrize("path", golden_files_v2("amp_"), ids=lambda p: p.split("/")[-1])
+def test_amplitude_edge_matches_reference_golden(path):
+    """High amplitudes against the real reference: HiFi-GAN outputs driven into tanh saturation (|o| up to exactly 1.0 ->
+    pcm 32737) and MB-iSTFT / MS / iSTFT outputs beyond +-1.0, where the reference's unclipped (int16_t)(o * 32737) wraps
+    around modulo 2^16 (SynthesizerTrn.cpp:393-396; the engine reproduces the x86 cast: devmath.hpp pcm_cast).  Waveform
+    tolerance scales with the peak (fp32 noise is relative); PCM within 1 LSB modulo 2^16."""
+    g, cfg, blob, utts, stride = load_golden_v2(path)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    for u, ids_u, sid_u, ls_u, dur_u, pcm_u, wave_u in utts:
+        syn.run_batch([ids_u], [sid_u], [ls_u])
+        assert (syn.durations(len(ids_u)) == dur_u).all()
+        wave = syn.tap("wave")[0][::stride].astype(np.float64)
+        peak = max(1.0, float(np.abs(wave_u).max()))
+        err = wave - wave_u.astype(np.float64)
+        assert np.sqrt((err ** 2).mean()) <= AMP_WAVE_RMSE_TOL * peak and np.abs(err).max() <= AMP_WAVE_MAXABS_TOL * peak, \
+            (path, float(np.sqrt((err ** 2).mean())), float(np.abs(err).max()), peak)
+        assert_pcm_close_wrapped(syn.pcm_host(), pcm_u, path)
+        if "wrap" in path:
+            assert (np.abs(wave_u) > 1.0009).mean() > 0.1          # the fixture really exercises the wrap-around
+            wrapped = np.abs(wave_u) * 32737 >= 32768
+            assert (syn.pcm_host()[wrapped] == pcm_u[wrapped]).mean() > 0.99
+        else:
+            assert np.abs(wave_u).max() > 0.85
+    syn.close()
+
+
+def test_pcm_cast_beyond_int32_matches_the_x86_reference_build():
+    """|o * 32737| >= 2^31 (and NaN): the reference build's cvttss2si yields 0x80000000, whose low 16 bits are 0; the
+    engine's pcm_cast reproduces that instead of the GPU's saturating conversion (which would give -1 for +overflow)."""
+    import dataclasses
+    cfg = dataclasses.replace(sb.tiny_cfg("mbb_fix"), mag_bias=30.0)       # |X_k| ~ e^30: far beyond int32 after scaling
+    blob = sb.make_blob(cfg, 5)
+    ids = sb.synthetic_ids(9, cfg.vocab)
+    o = (pyref.RefModel(blob) if pyref.have_ref() else pyref.PortModel(blob)).infer_ids(ids, 0, 1.0)
+    assert (np.abs(o["wave"]) * 32737 >= 2 ** 31).mean() > 0.5
+    pcm = engine.Synthesizer(blob).infer_ids(ids, 0, 1.0)
+    big = np.abs(o["wave"].astype(np.float64)) * 32737 >= 2.0 ** 31 * 1.001
+    assert (pcm[big] == 0).all() and (o["pcm"][big] == 0).all()
+
+
+def test_multi_device_entry_matches_single_engine():
+    """sts_multi_* (SURVEY 8b/8e): one process, an engine per listed device (here the one GPU twice), utterances sharded
+    longest-first by phoneme count, PCM back in input order."""
+    cfg = sb.tiny_cfg("ms_hifigan_sdp")
+    blob = sb.make_blob(cfg, 21)
+    syn = engine.Synthesizer(blob)
+    lens = [9, 31, 5, 17, 2, 24, 11]
+    ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate(lens)]
+    sid = [i % cfg.spk_num for i in range(len(lens))]
+    ls = [1.0 + 0.05 * i for i in range(len(lens))]
+    want = [syn.infer_ids(a, s, l) for a, s, l in zip(ids, sid, ls)]
+    md = engine.MultiDevice(blob, [0, 0, 0])
+    assert md.device_count() == 3
+    slot = md.shard_of(lens)
+    from summertts_amd import sharding
+    shards = sharding.shard_utterances(lens, 3)               # the python sharder of the one-process-per-GPU path: same rule
+    for k, sh in enumerate(shards):
+        assert all(slot[u] == k for u in sh)
+    got = md.infer_batch(ids, sid, ls)
+    for i in range(len(lens)):
+        assert_pcm_close(got[i], want[i], f"multi-device utterance {i}")
+    one = md.infer_batch(ids[:1], sid[:1], ls[:1])            # fewer utterances than devices: idle devices take no part
+    assert_pcm_close(one[0], want[0], "single utterance on a 3-slot handle")
+    with pytest.raises(engine.StsError):
+        md.infer_batch([[0, cfg.vocab + 1]])                  # a bad id fails the call, outputs released
+    with pytest.raises(engine.StsError):
+        engine.MultiDevice(blob, [0, 99])                     # device that does not exist
+    md.close()
+    syn.close()
+
+
+def test_wide_dilation_model_takes_the_checked_paths():
+    """a ResBlock whose later layers have dil * (k - 1) > 64 (k = 11, dilation 7) must not reach the grouped
+    matrix-core launch, whose staged LDS window cannot hold that halo; an attention window > 7 needs more than 16
+    relative-position logits.  Both against the oracle."""
+    import dataclasses
+    cfg = dataclasses.replace(sb.tiny_cfg("hifigan_fix"), res_k=(11, 3), res_d=((1, 7, 2), (1, 3, 9)), window=9)
+    blob = sb.make_blob(cfg, 8)
+    ids = sb.synthetic_ids(33, cfg.vocab, salt=1)
+    o = pyref.PortModel(blob).infer_ids(ids, 0, 1.0, taps=True)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    syn.run_batch([ids])
+    assert (syn.durations(len(ids)) == o["durations"]).all()
+    assert np.abs(syn.tap("x_enc") - o["x_enc"]).max() <= TAP_MAXABS_TOL
+    assert_wave_close(syn.tap("wave")[0], o["wave"], "wide dilation")
+    assert_pcm_close(syn.pcm_host(), o["pcm"], "wide dilation")
     syn.close()

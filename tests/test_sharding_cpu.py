@@ -48,6 +48,17 @@ def _worker(rank, world, port, q):
         q.put(ok)
     else:
         assert res is None and res1 is None and res2 is None
+    # shards of different sizes, one of them EMPTY, and max_utts left to the collective (all_reduce MAX): every rank
+    # must still build count tensors of the same length and join both collectives
+    lens3 = [9]
+    sh3 = sharding.shard_utterances(lens3, world)
+    assert [len(x) for x in sh3] == [1, 0]
+    pcs3 = [np.arange(lens3[u] * 2, dtype=np.int16) + 5 for u in sh3[rank]]
+    loc3 = torch.from_numpy(np.concatenate(pcs3)) if pcs3 else torch.zeros(0, dtype=torch.int16)
+    res3 = sharding.gather_variable(loc3, [p.size for p in pcs3], dist, torch, rank, world)
+    if rank == 0:
+        q.put(len(res3) == 2 and len(res3[1]) == 0 and np.array_equal(res3[0][0], np.arange(18, dtype=np.int16) + 5))
+    assert sharding.run_shard(None, [], [], []).size == 0          # an empty shard never touches the engine
     dist.destroy_process_group()
 
 
@@ -61,4 +72,5 @@ def test_gather_variable_gloo_world2():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    assert q.get(timeout=5) is True
     assert q.get(timeout=5) is True

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/full_*.npz and tests/golden/amp_*.npz with the REAL reference (oracle/_ref = the
+/root/reference sources compiled in place).  Run where /root/reference exists (minutes of CPU time); the
+fixtures travel to the GPU box, where the reference does not exist.
+
+  full_*  BASELINE.json configs[2]-[4] at FULL model size (upstream VITS / MB-iSTFT-VITS dims), at launch sizes
+          where the grouped / fused / Winograd kernels engage: single utterances of 64-96 phonemes and members of
+          ragged 8-utterance batches (the batch is defined by `batch_lens` / `batch_sids`; only the utterances in
+          `check_idx` carry reference outputs -- the rest of the batch is load).
+  amp_*   amplitude edge: tanh saturation of the HiFi-GAN tail (|o| -> 1.0) and MB-iSTFT / MS / iSTFT outputs
+          beyond +-1.0, where the reference's (int16_t)(o * 32737) wraps around (SynthesizerTrn.cpp:393-396).
+
+Stored per utterance u: ids_u, sid_u, ls_u, dur_u (reference durations), pcm_u (reference int16 PCM) and
+wave_u = the reference float waveform[::wave_stride] (full-size fixtures keep every 8th sample to stay small)."""
+import dataclasses
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyref                      # noqa: E402
+from summertts_amd import synth_blob as sb    # noqa: E402
+
+BATCH_LENS = np.random.default_rng(1234).integers(64, 257, size=8).tolist()   # bench.py --ragged, first 8
+
+
+def batch_case(kind, n_check, spk=1):
+    order = sorted(range(len(BATCH_LENS)), key=lambda i: BATCH_LENS[i])
+    return dict(kind=kind, size="full", batch_lens=BATCH_LENS, batch_sids=[(i * 29) % spk for i in range(len(BATCH_LENS))],
+                check_idx=sorted(order[:n_check]))
+
+
+CASES = {
+    # name: dict(kind, size, overrides, utts=[(T, salt, sid, ls)] | batch definition)
+    "full_mbb_fix_T96": dict(kind="mbb_fix", size="full", utts=[(96, 3, 0, 1.0)]),
+    "full_ms_sdp_T96": dict(kind="ms_sdp", size="full", utts=[(96, 4, 0, 1.0)]),
+    "full_ms_hifigan_sdp_T64": dict(kind="ms_hifigan_sdp", size="full", utts=[(64, 5, 0, 1.0), (64, 5, 57, 1.0), (64, 5, 173, 1.05)]),
+    "full_batch8_mbb_fix": batch_case("mbb_fix", 2),
+    "full_batch8_hifigan_sdp": batch_case("hifigan_sdp", 2),
+    "full_batch8_ms_hifigan_sdp": batch_case("ms_hifigan_sdp", 2, spk=174),
+    "amp_hifigan_fix_sat10": dict(kind="hifigan_fix", size="tiny", overrides=dict(post_gain=10.0), utts=[(20, 0, 0, 1.0)]),
+    "amp_hifigan_fix_sat30": dict(kind="hifigan_fix", size="tiny", overrides=dict(post_gain=30.0), utts=[(20, 0, 0, 1.0)]),
+    "amp_mbb_fix_wrap": dict(kind="mbb_fix", size="tiny", overrides=dict(mag_bias=3.0), utts=[(20, 0, 0, 1.0)]),
+    "amp_ms_sdp_wrap": dict(kind="ms_sdp", size="tiny", overrides=dict(mag_bias=3.5), utts=[(20, 0, 0, 1.0)]),
+    "amp_istft_fix_wrap": dict(kind="istft_fix", size="tiny", overrides=dict(istft_mag_bias=4.0), utts=[(20, 0, 0, 1.0)]),
+    "amp_full_hifigan_sdp_sat": dict(kind="hifigan_sdp", size="full", overrides=dict(post_gain=8.0), utts=[(12, 9, 0, 1.0)]),
+}
+
+
+def case_cfg(c):
+    cfg = sb.full_cfg(c["kind"]) if c["size"] == "full" else sb.tiny_cfg(c["kind"])
+    return dataclasses.replace(cfg, **c.get("overrides", {}))
+
+
+def case_utts(c, vocab):
+    """[(index in the batch, ids, sid, ls)] of the utterances that carry reference outputs."""
+    if "utts" in c:
+        return [(u, sb.synthetic_ids(T, vocab, salt=salt), sid, ls) for u, (T, salt, sid, ls) in enumerate(c["utts"])]
+    return [(u, sb.synthetic_ids(int(c["batch_lens"][u]), vocab, salt=u), int(c["batch_sids"][u]), 1.0) for u in c["check_idx"]]
+
+
+def main():
+    pyref.build(port=False, ref=True)
+    only = sys.argv[1:]
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, c in CASES.items():
+        if only and name not in only:
+            continue
+        cfg = case_cfg(c)
+        blob = sb.make_blob(cfg, 1234)
+        ref = pyref.RefModel(blob)
+        assert ref.consumed == blob.size
+        stride = 8 if c["size"] == "full" and name.startswith("full_") else 1
+        rec = dict(kind=c["kind"], size=c["size"], overrides=json.dumps(c.get("overrides", {})), seed=1234,
+                   blob_sha256=hashlib.sha256(blob.tobytes()).hexdigest(), wave_stride=stride)
+        if "batch_lens" in c:
+            rec.update(batch_lens=np.asarray(c["batch_lens"], np.int32), batch_sids=np.asarray(c["batch_sids"], np.int32))
+        idx = []
+        for u, ids, sid, ls in case_utts(c, cfg.vocab):
+            t0 = time.time()
+            o = ref.infer_ids(ids, sid, ls)
+            idx.append(u)
+            rec.update({f"ids_{u}": ids, f"sid_{u}": sid, f"ls_{u}": np.float32(ls), f"dur_{u}": o["durations"],
+                        f"pcm_{u}": o["pcm"], f"wave_{u}": o["wave"][::stride].copy()})
+            w = o["wave"]
+            print(f"{name}[{u}]: T={ids.size} sid={sid} frames={int(o['durations'].sum())} samples={w.size} "
+                  f"max|o|={np.abs(w).max():.4f} frac(|o|>0.8)={(np.abs(w) > 0.8).mean():.3f} frac(|o|>1)={(np.abs(w) > 1.0009).mean():.3f} "
+                  f"({time.time() - t0:.1f} s)", flush=True)
+        rec["utts"] = np.asarray(idx, np.int32)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+        ref.close()
+
+
+if __name__ == "__main__":
+    main()
