@@ -275,27 +275,28 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
     const int out_off = a.out_off + phase;
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
     if (a.epi == EPI_GATE) {
-        if constexpr (MW == 2) {
-            if (mvalid[0]) {
-                static_for<0, NW>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    const int n = n0 + wn * NW * 32 + q * 32 + l31;
-                    const int pos = n * a.out_stride + out_off;
-                    if (n < n_count && pos >= 0 && pos < out_len) {
-                        const size_t opos = out_base + (size_t)pos;
-                        static_for<0, 16>([&](auto rc) {
-                            constexpr int r = decltype(rc)::value;
-                            const int rowp = mbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            float vt = acc[0][q][r], vs = acc[1][q][r];
-                            if (a.bias) { vt += a.bias[rowp]; vs += a.bias[rowp + 32]; }
-                            if (a.ubias) { vt += a.ubias[(size_t)rowp * a.ubias_ld + b]; vs += a.ubias[(size_t)(rowp + 32) * a.ubias_ld + b]; }
-                            const int ch = (rowp >> 6) * 32 + (rowp & 31);
-                            if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(vt) * sigmoid_ref(vs);
-                        });
-                    }
-                });
-            }
-        }
+        // rows r and r + 8 of a lane's 16 accumulator rows are tile rows (c, c + 16): the tanh and the sigmoid
+        // pre-activation of one channel (model.hip gate_perm_row)
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, NW>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int n = n0 + wn * NW * 32 + q * 32 + l31;
+                const int pos = n * a.out_stride + out_off;
+                if (mvalid[i] && n < n_count && pos >= 0 && pos < out_len) {
+                    const size_t opos = out_base + (size_t)pos;
+                    static_for<0, 8>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float vt = acc[i][q][r], vs = acc[i][q][r + 8];
+                        if (a.bias) { vt += a.bias[rowp]; vs += a.bias[rowp + 16]; }
+                        if (a.ubias) { vt += a.ubias[(size_t)rowp * a.ubias_ld + b]; vs += a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b]; }
+                        const int ch = (rowp >> 5) * 16 + (rowp & 15);
+                        if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(vt) * sigmoid_ref(vs);
+                    });
+                }
+            });
+        });
         return;
     }
     static_for<0, MW>([&](auto ic) {
@@ -1036,12 +1037,13 @@ void resblock_wino_kernel(ResLayerGroup G, int nx) {
 // the KS partial accumulators are summed through LDS once, followed by the same fused epilogues.
 // ------------------------------------------------------------------------------------------------
 template <int MW, int NW>
-__global__ __launch_bounds__(MW * NW <= 2 ? 1024 : 256) void conv_mfma_splitk_kernel(ConvArgs a, int mtiles) {
+__global__ __launch_bounds__(1024) void conv_mfma_splitk_kernel(ConvArgs a, int mtiles) {
     constexpr int G = 4, E = MW * NW * 16;
     constexpr int D = MW * NW == 1 ? 6 : (MW * NW == 2 ? 4 : 3);   // register ring depth (groups in flight)
     extern __shared__ __attribute__((aligned(16))) float red[];   // [KS][E][64]
     const int KS = blockDim.x >> 6;
-    const int b = blockIdx.z;
+    const int nsl = a.kslices > 1 ? a.kslices : 1;
+    const int b = blockIdx.z / nsl, slice = blockIdx.z - b * nsl;
     const int orig_len = seg_len(a.in_seg, b);
     const int in_len = orig_len + (a.in_reflect ? 1 : 0);
     const int out_len = seg_len(a.out_seg, b);
@@ -1071,7 +1073,10 @@ __global__ __launch_bounds__(MW * NW <= 2 ? 1024 : 256) void conv_mfma_splitk_ke
     // SCALAR registers (no integer division, no 64-bit vector address arithmetic): both operands go
     // through raw buffer descriptors with the uniform part of the address in the scalar offset.
     const int gpt = a.Cin_pad / (2 * G);   // groups per tap
-    const int ngroups = a.ntap * gpt;
+    const int gall = a.ntap * gpt;
+    const int gper = (gall + nsl - 1) / nsl;
+    const int gfirst = slice * gper;                                   // this workgroup's share of K: groups [gfirst, ngroups)
+    const int ngroups = gfirst + gper < gall ? gfirst + gper : gall;
     float ra[D][G][MW], rb[D][G][NW];
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int sKS = __builtin_amdgcn_readfirstlane(KS);
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(MW * NW <= 2 ? 1024 : 256) void conv_mfma_splitk_ke
     const unsigned x_lane = (unsigned)half * ld4;                                       // odd channel of a pair
     const unsigned a_lane = (unsigned)(((size_t)half * a.Cout_pad + m0 + l31) * 4);
     const int lanepos = n0 + l31;
-    int lj = swave / gpt, lc = (swave - lj * gpt) * 2 * G;     // (tap, first channel) of the next group to LOAD
+    int lj = (gfirst + swave) / gpt, lc = (gfirst + swave - lj * gpt) * 2 * G;     // (tap, first channel) of the next group to LOAD
     const int jstep = sKS / gpt, cstep = (sKS - jstep * gpt) * 2 * G;
 
     auto load_group = [&](float (&fa)[G][MW], float (&fb)[G][NW]) {
@@ -1115,10 +1120,10 @@ __global__ __launch_bounds__(MW * NW <= 2 ? 1024 : 256) void conv_mfma_splitk_ke
         if (lc >= a.Cin_pad) { lc -= a.Cin_pad; lj++; }
     };
 
-    int gnext = swave;
+    int gnext = gfirst + swave;
 #pragma unroll
     for (int d = 0; d < D; d++) { if (gnext < ngroups) load_group(ra[d], rb[d]); gnext += sKS; }
-    int gcur = swave;
+    int gcur = gfirst + swave;
     while (gcur < ngroups) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -1158,10 +1163,11 @@ __global__ __launch_bounds__(MW * NW <= 2 ? 1024 : 256) void conv_mfma_splitk_ke
     __syncthreads();
     const int out_off = a.out_off + phase;
     const bool gate = a.epi == EPI_GATE;
-    const int nelem = gate ? NW * 16 : E;    // gate: the (tanh, sigmoid) tile pair is handled together
-    for (int e = wave; e < nelem; e += KS) {
-        const int i = gate ? 0 : e / (NW * 16);
+    // gate: tile rows (c, c + 16) = accumulator rows (r, r + 8) are the (tanh, sigmoid) pair of one channel
+    for (int e = wave; e < E; e += KS) {
+        const int i = e / (NW * 16);
         const int q = (e >> 4) % NW, r = e & 15;
+        if (gate && r >= 8) continue;
         const int n = n0 + q * 32 + l31;
         const int pos = n * a.out_stride + out_off;
         if (n >= n_count || pos < 0 || pos >= out_len) continue;
@@ -1170,16 +1176,21 @@ __global__ __launch_bounds__(MW * NW <= 2 ? 1024 : 256) void conv_mfma_splitk_ke
         float v = 0.f, v2 = 0.f;
         for (int k = 0; k < KS; k++) {
             v += red[((size_t)k * E + (i * NW + q) * 16 + r) * 64 + lane];
-            if (gate) v2 += red[((size_t)k * E + (NW + q) * 16 + r) * 64 + lane];
+            if (gate) v2 += red[((size_t)k * E + (i * NW + q) * 16 + r + 8) * 64 + lane];
         }
         if (gate) {
-            if (MW < 2 || !mvalid[0]) continue;
-            if (a.bias) { v += a.bias[rowp]; v2 += a.bias[rowp + 32]; }
-            if (a.ubias) { v += a.ubias[(size_t)rowp * a.ubias_ld + b]; v2 += a.ubias[(size_t)(rowp + 32) * a.ubias_ld + b]; }
-            const int ch = (rowp >> 6) * 32 + (rowp & 31);
+            if (!mvalid[i]) continue;
+            if (a.bias) { v += a.bias[rowp]; v2 += a.bias[rowp + 16]; }
+            if (a.ubias) { v += a.ubias[(size_t)rowp * a.ubias_ld + b]; v2 += a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b]; }
+            const int ch = (rowp >> 5) * 16 + (rowp & 15);
             if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(v) * sigmoid_ref(v2);
         } else {
             if (rowp >= a.Cout) continue;
+            if (nsl > 1) {      // partial sum of one K slice (EPI_STORE only): bias on slice 0, the consumer adds the slices
+                if (slice == 0) { if (a.bias) v += a.bias[rowp]; if (a.ubias) v += a.ubias[(size_t)rowp * a.ubias_ld + b]; }
+                a.y[(size_t)slice * a.kslice_stride + (size_t)rowp * a.y_ld + opos] = v;
+                continue;
+            }
             if (a.bias) v += a.bias[rowp];
             if (a.ubias) v += a.ubias[(size_t)rowp * a.ubias_ld + b];
             epi_scalar(a, rowp, opos, v);
@@ -1208,7 +1219,7 @@ bool conv_mfma_eligible(const ConvArgs& a) {
     int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
     int halo = first < last ? last - first : first - last;
     if (halo > MAX_HALO) return false;
-    if (a.epi == EPI_GATE && (!a.gate_perm || a.Cout_pad % 64 != 0)) return false;
+    if (a.epi == EPI_GATE && !a.gate_perm) return false;
     if (a.epi == EPI_TANH_PCM) return false;
     return true;
 }
@@ -1216,10 +1227,9 @@ bool conv_mfma_eligible(const ConvArgs& a) {
 // Tile choice, from tools/conv_bench.py on MI355X (profiles/r01_conv_microbench.log).  All candidates are
 // 128 columns wide (4 waves x 32 columns); a wave owns a 64-row strip (A fragment reused over two row
 // tiles) when the output rows fill it and the launch still yields >= 2 workgroups per CU, else a 32-row
-// strip; below one workgroup per CU the split-K kernel takes over (launch_splitk).  The gated WaveNet
-// conv needs the (tanh, sigmoid) row-tile pair in one wave: 64x128.
+// strip; below one workgroup per CU the split-K kernel takes over (launch_splitk).  The gated WaveNet conv carries its
+// (tanh, sigmoid) pairs inside every 32-row tile, so it takes part in the same choice.
 static int pick_tile(const ConvArgs& a, int nphase) {
-    if (a.epi == EPI_GATE) return 3;
     const long nt = (a.max_n + 127) / 128;
     if (a.Cout_pad % 64 == 0 && nt * (a.Cout_pad / 64) * nphase * a.B >= 512) return 3;
     return 4;
@@ -1238,16 +1248,17 @@ template <int MW, int NW>
 static void launch_splitk(const ConvArgs& a, int nphase, hipStream_t st) {
     const int mt = (a.Cout_pad + 32 * MW - 1) / (32 * MW);
     const int nt = (a.max_n + 32 * NW - 1) / (32 * NW);
-    const long steps = (long)a.ntap * (a.Cin_pad / 8);          // groups of 4 channel pairs
+    const int nsl = a.kslices > 1 ? a.kslices : 1;
+    const long steps = ((long)a.ntap * (a.Cin_pad / 8) + nsl - 1) / nsl;          // groups of 4 channel pairs (per K slice)
     constexpr int E = MW * NW * 16;
     // LDS for the partial tiles: <= 64 KiB normally; a grid that cannot even give every CU one workgroup may take
     // 128 KiB (16 waves on a two-tile workgroup: half the dependent L2/HBM round trips per wave)
-    const bool sparse = (long)mt * nt * nphase * a.B <= 256;
+    const bool sparse = (long)mt * nt * nphase * a.B * nsl <= 256;
     const int ks_cap = E <= 16 ? 16 : (E <= 32 ? (sparse ? 16 : 8) : 4);
     // enough waves that each one issues >= ~6 groups (24 MFMA rounds), but do not drown the chip
     int ks = 1;
-    while (ks < ks_cap && steps / (ks * 2) >= 6 && (long)mt * nt * nphase * a.B * ks * 2 <= 4096) ks *= 2;
-    dim3 grid(nt, mt * nphase, a.B);
+    while (ks < ks_cap && steps / (ks * 2) >= 6 && (long)mt * nt * nphase * a.B * nsl * ks * 2 <= 4096) ks *= 2;
+    dim3 grid(nt, mt * nphase, a.B * nsl);
     size_t lds = (size_t)ks * E * 64 * sizeof(float);
     hipLaunchKernelGGL((conv_mfma_splitk_kernel<MW, NW>), grid, dim3(ks * 64), lds, st, a, mt);
 }
@@ -1399,9 +1410,9 @@ void conv_mfma_group(const ConvGroup& Gin, hipStream_t st, int tile) {
 void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
     int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
-    const bool gate = a.epi == EPI_GATE;
-    bool splitk = tile == 6 || tile == 7;
+    bool splitk = tile == 6 || tile == 7 || a.kslices > 1;
     int nw = tile == 7 ? 2 : 1;
+    if (a.kslices > 1 && tile != 7) tile = 6;
     if (tile < 0 || tile > 7) {
         tile = pick_tile(a, nphase);
         const TileCfg& t = kTiles[tile];
@@ -1410,11 +1421,9 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
         if (blocks < 256 && (double)a.Cin_pad * (double)a.x_ld * 4.0 < 2.0e9) { splitk = true; nw = ((a.max_n + 63) / 64) * ((a.Cout_pad + 31) / 32) * nphase * (long)a.B >= 512 ? 2 : 1; }
     }
     if (splitk) {
-        if (gate) { if (nw == 2) launch_splitk<2, 2>(a, nphase, st); else launch_splitk<2, 1>(a, nphase, st); }
-        else { if (nw == 2) launch_splitk<1, 2>(a, nphase, st); else launch_splitk<1, 1>(a, nphase, st); }
+        if (nw == 2) launch_splitk<1, 2>(a, nphase, st); else launch_splitk<1, 1>(a, nphase, st);
         return;
     }
-    if (gate && kTiles[tile].MW != 2) tile = 3;
     switch (tile) {
         case 0: launch_mfma<2, 2, 2, 2>(a, nphase, st); break;
         case 1: launch_mfma<2, 2, 1, 4>(a, nphase, st); break;
@@ -1446,7 +1455,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a, int rows)
     // gate: rows (c, c + H) unless the weights were tile-permuted for the matrix-core kernel
     int row2 = row + a.H;
     int rowp = row;
-    if (gate && a.gate_perm) { rowp = (row >> 5) * 64 + (row & 31); row2 = rowp + 32; }
+    if (gate && a.gate_perm) { rowp = (row >> 4) * 32 + (row & 15); row2 = rowp + 16; }
     float v = 0.f, v2 = 0.f;
     if (a.depthwise) {
         const float* xrow = a.x + (size_t)row * a.x_ld + in_base;

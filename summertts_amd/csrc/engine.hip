@@ -108,6 +108,7 @@ ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float
     a.in_act = o.in_act; a.in_slope = o.slope; a.in_reflect = o.reflect;
     a.epi = o.epi; a.epi_flag = o.epi_flag; a.epi_scale = o.epi_scale; a.H = c.H; a.gate_perm = c.gate_perm;
     a.in_seg = lin.seg; a.out_seg = lout.seg; a.B = lout.nb;
+    a.kslices = o.kslices; a.kslice_stride = o.kslice_stride;
     const double positions = c.transposed ? (double)lin.total : (double)lout.total;
     const double fl = 2.0 * c.macs_per_out * positions;
     flops_[cur_stage_] += fl;
@@ -127,16 +128,29 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
     if (can_mfma) {
         if (in_mfma_region_) { mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_++; }
-        conv_mfma(a, cur_, conv_mode >= 2 ? conv_mode - 2 : -1);
+        conv_mfma(a, cur_, o.tile >= 0 ? o.tile : (conv_mode >= 2 ? conv_mode - 2 : -1));
     } else {
         conv_generic(a, cur_);
     }
 }
 
-void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu) {
+// Cross-workgroup K split for a conv whose output has too few tiles to fill the chip while its K loop is long (text-encoder
+// FFN second conv at batch 1: 24 tiles x K = 2304): slices are sized so that about one workgroup per CU results and
+// every slice keeps >= 24 groups of 8 input channels.  1 = no split.
+int Engine::pick_kslices(const DConv& c, const Lvl& lout) const {
+    if (conv_mode != 0 || c.depthwise || c.transposed || c.Cin < 32) return 1;
+    const long tiles = (long)((lout.max_len + 31) / 32) * (c.Cout_pad / 32) * lout.nb;
+    const long groups = (long)c.k * (c.Cin_pad / 8);
+    int s = 1;
+    while (s < 8 && tiles * (s * 2) <= 256 && groups / (s * 2) >= 24) s *= 2;
+    return s;
+}
+
+void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu, int nb, long b_stride) {
     LnArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.a_ld = lv.ld; g.b = b; g.b_ld = lv.ld; g.res = res; g.res_ld = lv.ld; g.y = y; g.y_ld = lv.ld;
+    g.nb = nb; g.b_stride = b_stride;
     g.gamma = l.g; g.beta = l.b; g.C = l.C; g.pre_relu = pre_relu; g.post_gelu = post_gelu;
     g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
     bytes_[cur_stage_] += 4.0 * (double)l.C * (double)lv.total * (2.0 + (b ? 1.0 : 0.0) + (res ? 1.0 : 0.0));
@@ -237,6 +251,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     const int wnH = M.n_flows ? M.cp[0].wn.H : 0;
     const int wnL = M.n_flows ? M.cp[0].wn.n : 0;
 
+    Lvl lvT; lvT.nb = B; lvT.max_len = maxT; lvT.total = Ttot; lvT.ld = Ttot;
+    const int ffn2_slices = M.n_layers ? pick_kslices(M.ffn[0].c2, lvT) : 1;
     BufT bt;
     auto layoutT = [&](Arena& A) {
         A.used = 0;
@@ -245,7 +261,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         bt.ids = A.get<int>(Ttot);
         bt.forced = A.get<int>(Ttot);
         bt.x = A.get<float>((size_t)H * Ttot); bt.qkv = A.get<float>((size_t)3 * H * Ttot);
-        bt.att = A.get<float>((size_t)H * Ttot); bt.y = A.get<float>((size_t)H * Ttot);
+        bt.att = A.get<float>((size_t)H * Ttot); bt.y = A.get<float>((size_t)H * Ttot * ffn2_slices);
         bt.x1 = A.get<float>((size_t)H * Ttot); bt.ffh = A.get<float>((size_t)FF * Ttot);
         bt.m = A.get<float>((size_t)C * Ttot);
         bt.dh = A.get<float>((size_t)(fdp > H ? fdp : H) * Ttot); bt.dt1 = A.get<float>((size_t)fdp * Ttot);
@@ -285,7 +301,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     HIPCK(hipMemcpyAsync(bt.ids, p_ids, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
     if (have_forced) HIPCK(hipMemcpyAsync(bt.forced, p_forced, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
 
-    Lvl lvT; lvT.seg = SegView{d_offT, d_lenT, 1, 0}; lvT.nb = B; lvT.max_len = maxT; lvT.total = Ttot; lvT.ld = Ttot;
+    lvT.seg = SegView{d_offT, d_lenT, 1, 0};
     Lvl lvB; lvB.seg = SegView{d_one, d_one + 1, 1, 0}; lvB.nb = 1; lvB.max_len = B; lvB.total = B; lvB.ld = B;
 
     mark(0);
@@ -309,8 +325,10 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         ConvOpt o1; o1.pad_l = f.ksize == 1 ? 0 : (f.ksize - 1) / 2;
         conv(f.c1, bt.x1, lvT, bt.ffh, lvT, o1);
         ConvOpt o2 = o1; o2.in_act = 1; o2.slope = 0.f;   // nn_relu fused into the consumer's staging
+        // few output tiles, long K: split K over workgroups into partial outputs that the LayerNorm below adds up
+        o2.kslices = ffn2_slices; o2.kslice_stride = (long)H * Ttot;
         conv(f.c2, bt.ffh, lvT, bt.y, lvT, o2);
-        ln(M.ln2[l], bt.x1, bt.y, nullptr, bt.x, lvT, 0, 0);
+        ln(M.ln2[l], bt.x1, bt.y, nullptr, bt.x, lvT, 0, 0, ffn2_slices, (long)H * Ttot);
     }
     conv(M.proj, bt.x, lvT, bt.m, lvT, ConvOpt());
     tap("x_enc", bt.x, H, Ttot, Ttot);
@@ -480,6 +498,10 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         float* reg = (i & 1) ? bf.regB : bf.regA;
         float* bup = reg;
         ConvOpt ou; ou.in_act = 1; ou.slope = 0.1f;
+        {   // experiment knob: per-stage kernel variant of the upsamplers, e.g. STS_UP_TILE=6--- (digit = conv mode - 2, '-' = automatic)
+            static const char* ut = getenv("STS_UP_TILE");
+            if (ut && (int)strlen(ut) > i && ut[i] >= '0' && ut[i] <= '7') ou.tile = ut[i] - '0';
+        }
         conv(up, x, lx, bup, l2, ou);
         // The nResK ResBlock chains only meet in the final sum (Generator_hifigan.cpp:159-173;
         // /root/reference/src/modules/ResBlock1.cpp:55-69 per chain).

@@ -37,6 +37,8 @@ struct ConvOpt {
     int16_t* pcm = nullptr;
     const float* ubias = nullptr;
     int pad_l = -1;            // override the left padding (FFN same_padding)
+    int tile = -1;             // force a kernel variant for this conv (as sts_set_conv_mode - 2); -1 = automatic
+    int kslices = 1; long kslice_stride = 0;   // cross-workgroup split of K into partial outputs (kernels.hpp ConvArgs::kslices)
 };
 
 // streaming decode: PCM is handed to `cb` chunk by chunk (cb returns non-zero to stop)
@@ -73,7 +75,8 @@ private:
     bool ensure_pinned(size_t bytes);
     ConvArgs conv_args(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o, double* flops);
     void conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o);
-    void ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu);
+    void ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu, int nb = 1, long b_stride = 0);
+    int pick_kslices(const DConv& c, const Lvl& lout) const;
     void dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv);
     void tap(const char* name, const float* d, int channels, long ld, long length);
     void stage_begin(int s);

@@ -46,9 +46,14 @@ struct ConvArgs {
     int in_act; float in_slope;     // input activation: 0 none, 1 leaky-relu(slope) (slope 0 == relu)
     int in_reflect;                 // logical input = reflect-pad-left-1 view of x (MB-iSTFT tail)
     int epi, epi_flag; float epi_scale; int H;
-    int gate_perm;                  // EPI_GATE rows are packed in (tanh32, sigmoid32) tile pairs
+    int gate_perm;                  // EPI_GATE rows are packed as (tanh16, sigmoid16) inside every 32-row tile
     SegView in_seg, out_seg;
     int B, max_n;                   // batch size, max n_count over the batch (grid sizing)
+    // cross-workgroup split of K (split-K kernel only, EPI_STORE only): slice s of `kslices` accumulates its share of the
+    // (tap, channel) groups and writes a PARTIAL output to y + s * kslice_stride (bias rides on slice 0); the consumer
+    // (layer_norm: LnArgs::nb) adds the partials up.  For convs with a long K and too few output tiles to fill the chip
+    // (FFN second conv at batch 1: K = 2304 over 24 tiles).
+    int kslices; long kslice_stride;
     // optional Winograd form of the same weights (conv_wino_*): [seg][4][Cin_pad][Cout_pad], see wino_pack()
     const float* wu; int wino_n3, wino_n2;
 };
@@ -63,8 +68,9 @@ bool conv_wino_eligible(const ConvArgs& a);
 void conv_wino(const ConvArgs& a, hipStream_t st);
 
 struct LnArgs {
-    const float* a; long a_ld;      // v = a (+ b)
-    const float* b; long b_ld;
+    const float* a; long a_ld;      // v = a (+ b_0 + b_1 + ... + b_{nb-1}, in this order)
+    const float* b; long b_ld;      // b_p = b + p * b_stride (split-K partial outputs of the producing conv); nb <= 1: one operand
+    int nb; long b_stride;
     const float* res; long res_ld;  // out = res + f(v) when non-null
     float* y; long y_ld;
     const float* gamma; const float* beta;

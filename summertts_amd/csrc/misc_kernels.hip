@@ -61,7 +61,11 @@ __device__ __forceinline__ float ln_input(const LnArgs& a, int c, size_t p, int 
     } else {
         v = a.a[(size_t)c * a.a_ld + p];
     }
-    if (a.b) v += a.b[(size_t)c * a.b_ld + p];
+    if (a.b) {
+        float bs = a.b[(size_t)c * a.b_ld + p];
+        for (int q = 1; q < a.nb; q++) bs += a.b[(size_t)q * a.b_stride + (size_t)c * a.b_ld + p];   // split-K partials, fixed order
+        v += bs;
+    }
     if (a.pre_relu && v < 0.f) v = 0.f;
     return v;
 }

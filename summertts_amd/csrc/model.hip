@@ -67,9 +67,12 @@ struct Store {
     }
 };
 
-int gate_perm_row(int pr, int H) {   // packed row -> source row for the (tanh32, sigmoid32) tile pairing
-    int g = pr / 64, r = pr % 64;
-    return r < 32 ? g * 32 + r : H + g * 32 + (r - 32);
+// packed row -> source row for the gate pairing: every 32-row MFMA tile holds 16 tanh rows followed by the 16 sigmoid
+// rows of the SAME channels, so that one accumulator tile carries complete (t, s) pairs in each lane (rows r and r + 16
+// of a 32x32 tile live in the same lane) and a 32-row tile is a legal unit of work for the gated conv
+int gate_perm_row(int pr, int H) {
+    int g = pr / 32, r = pr % 32;
+    return r < 16 ? g * 16 + r : H + g * 16 + (r - 16);
 }
 
 bool pack_conv(Store& st, const HConv& h, const PackOpts& o, DConv& d) {
@@ -80,16 +83,16 @@ bool pack_conv(Store& st, const HConv& h, const PackOpts& o, DConv& d) {
     d.Cout = rows;
     d.k = h.k; d.pad = h.pad; d.dil = h.dil;
     d.Cin_pad = round_up(d.Cin, 16);
-    const bool perm = o.gate && (o.gate_H % 32 == 0);
+    const bool perm = o.gate && (o.gate_H % 16 == 0);
     d.gate_perm = perm ? 1 : 0;
     d.H = o.gate_H;
-    d.Cout_pad = round_up(rows, perm ? 64 : 32);
+    d.Cout_pad = round_up(rows, 32);
     d.macs_per_out = o.depthwise ? (double)rows * h.k : (double)d.Cin * rows * h.k;
     auto src_row = [&](int pr) -> int {
         if (pr >= rows) return -1;
         if (o.reverse_out) return rows - 1 - pr;
         if (perm) return gate_perm_row(pr, o.gate_H);
-        if (o.gate_blocks && o.gate_H % 32 == 0) {
+        if (o.gate_blocks && o.gate_H % 16 == 0) {
             int blk = pr / (2 * o.gate_H), within = pr % (2 * o.gate_H);
             return blk * 2 * o.gate_H + gate_perm_row(within, o.gate_H);
         }

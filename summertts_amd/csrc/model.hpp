@@ -38,7 +38,7 @@ struct DLn { int C = 0; const float* g = nullptr; const float* b = nullptr; };
 struct PackOpts {
     bool reverse_in = false;    // input channels in reversed order (flow flip folded in)
     bool reverse_out = false;   // output rows in reversed order
-    bool gate = false;          // WN in_layer: rows become (tanh32, sigmoid32) tile pairs when H % 32 == 0
+    bool gate = false;          // WN in_layer: rows become (tanh16, sigmoid16) groups inside every 32-row tile when H % 16 == 0
     int gate_H = 0;
     bool gate_blocks = false;   // cond_layer: apply the gate permutation inside every 2H-row block
     bool depthwise = false;
