@@ -53,8 +53,8 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned byte_off) {
 }
 constexpr unsigned kOOB = 0x7FFFFFF0u;   // byte offset that is out of range for every descriptor
 
-__device__ __forceinline__ int seg_start(const SegView& s, int b) { return s.off[b] * s.scale + b * s.extra; }
-__device__ __forceinline__ int seg_len(const SegView& s, int b) { return s.len[b] * s.scale + s.extra; }
+__device__ __forceinline__ int seg_start(const SegView& s, int b) { return (s.off ? s.off[b] : s.ioff) * s.scale + b * s.extra; }
+__device__ __forceinline__ int seg_len(const SegView& s, int b) { return (s.off ? s.len[b] : s.ilen) * s.scale + s.extra; }
 
 // logical input sample (zero padding, optional reflect-left-1 view, fused input activation)
 __device__ __forceinline__ float load_in(const ConvArgs& a, const float* xrow, int pos, int in_len, int orig_len) {
@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(1024) void conv_mfma_splitk_kernel(ConvArgs a, int 
     const int gall = a.ntap * gpt;
     const int gper = (gall + nsl - 1) / nsl;
     const int gfirst = slice * gper;                                   // this workgroup's share of K: groups [gfirst, ngroups)
-    const int ngroups = gfirst + gper < gall ? gfirst + gper : gall;
+    const int ngroups = (STS_EXP & 64) ? gfirst : (gfirst + gper < gall ? gfirst + gper : gall);   // EXP 64: no K loop at all
     float ra[D][G][MW], rb[D][G][NW];
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int sKS = __builtin_amdgcn_readfirstlane(KS);

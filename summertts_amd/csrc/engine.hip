@@ -158,13 +158,39 @@ void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, 
 }
 
 // /root/reference/src/modules/DDSConv.cpp:84-111: x += gelu(LN2(conv1x1(gelu(LN1(dwconv(x))))))
-void Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv) {
+// Returns the buffer that holds the result (h or t1: the fused layers ping-pong between them).
+float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv) {
+    static const bool no_col = getenv("STS_NO_COL_LAYER") != nullptr;   // experiment knob
+    float* cur = h;
     for (int i = 0; i < d.n; i++) {
+        const DConv& c = d.sep[i];
+        const DConv& pw = d.pw[i];
+        if (!no_col && conv_mode != 1 && !pw.depthwise && pw.k == 1 && pw.Cin == pw.Cout && pw.Cin == d.n1[i].C && pw.Cin == d.n2[i].C &&
+            pw.Cin_pad == pw.Cin) {
+            // the whole layer as ONE launch (col_layer.hip); output goes to the other buffer: neighbouring workgroups still
+            // read `cur` through the dilated depthwise taps
+            ColLayerArgs g;
+            memset(&g, 0, sizeof(g));
+            float* nxt = cur == h ? t1 : h;
+            g.x = cur; g.x_ld = lv.ld;
+            g.dw_w = c.w; g.dw_b = c.bias; g.dw_k = c.k; g.dw_dil = c.dil; g.dw_pad = c.pad; g.dw_ld = c.Cout_pad;
+            g.g1 = d.n1[i].g; g.b1 = d.n1[i].b;
+            g.wc = pw.wc; g.bias = pw.bias;
+            g.g2 = d.n2[i].g; g.b2 = d.n2[i].b; g.post_gelu = 1;
+            g.res = cur; g.res_ld = lv.ld; g.y = nxt; g.y_ld = lv.ld; g.C = pw.Cin;
+            g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
+            if (col_layer_eligible(g)) {
+                flops_[cur_stage_] += 2.0 * (c.macs_per_out + pw.macs_per_out) * (double)lv.total;
+                bytes_[cur_stage_] += 4.0 * ((double)pw.Cin * lv.total * 2.0 + (double)pw.Cin * pw.Cout);
+                col_layer(g, cur_);
+                cur = nxt;
+                continue;
+            }
+        }
         {   // depthwise conv fused into the LayerNorm that consumes it (one launch instead of two)
-            const DConv& c = d.sep[i];
             LnArgs g;
             memset(&g, 0, sizeof(g));
-            g.a = h; g.a_ld = lv.ld; g.y = t1; g.y_ld = lv.ld;
+            g.a = cur; g.a_ld = lv.ld; g.y = t2; g.y_ld = lv.ld;
             g.gamma = d.n1[i].g; g.beta = d.n1[i].b; g.C = d.n1[i].C; g.post_gelu = 1;
             g.dw_w = c.w; g.dw_b = c.bias; g.dw_k = c.k; g.dw_dil = c.dil; g.dw_pad = c.pad; g.dw_ld = c.Cout_pad;
             g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
@@ -172,9 +198,11 @@ void Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv) {
             bytes_[cur_stage_] += 4.0 * (double)g.C * (double)lv.total * 2.0;
             layer_norm(g, cur_);
         }
-        conv(d.pw[i], t1, lv, t2, lv, ConvOpt());
-        ln(d.n2[i], t2, nullptr, h, h, lv, 0, 1);
+        float* other = cur == h ? t1 : h;       // conv output; `cur` stays the residual and is updated in place
+        conv(pw, t2, lv, other, lv, ConvOpt());
+        ln(d.n2[i], other, nullptr, cur, cur, lv, 0, 1);
     }
+    return cur;
 }
 
 void Engine::tap(const char* name, const float* d, int channels, long ld, long length) {
@@ -301,8 +329,12 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     HIPCK(hipMemcpyAsync(bt.ids, p_ids, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
     if (have_forced) HIPCK(hipMemcpyAsync(bt.forced, p_forced, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
 
-    lvT.seg = SegView{d_offT, d_lenT, 1, 0};
-    Lvl lvB; lvB.seg = SegView{d_one, d_one + 1, 1, 0}; lvB.nb = 1; lvB.max_len = B; lvB.total = B; lvB.ld = B;
+    // single-segment views travel by value (kernels.hpp SegView): no segment-table load in the kernels of a one-utterance call
+    static const bool no_inline_seg = getenv("STS_NO_INLINE_SEG") != nullptr;   // experiment knob
+    const bool inl = B == 1 && !no_inline_seg;
+    lvT.seg = inl ? SegView{nullptr, nullptr, 1, 0, 0, lenT[0]} : SegView{d_offT, d_lenT, 1, 0, 0, 0};
+    Lvl lvB; lvB.seg = no_inline_seg ? SegView{d_one, d_one + 1, 1, 0, 0, 0} : SegView{nullptr, nullptr, 1, 0, 0, B};
+    lvB.nb = 1; lvB.max_len = B; lvB.total = B; lvB.ld = B;
 
     mark(0);
     // ---------------- TextEncoder (/root/reference/src/models/TextEncoder.cpp:50-74, attention_encoder.cpp:78-94)
@@ -319,8 +351,22 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         attention(at, stream);
         flops_[0] += 2.0 * 2.0 * (double)a.ch * (double)maxT * (double)Ttot;   // ~ QK^T + PV
         bytes_[0] += 4.0 * 4.0 * (double)H * (double)Ttot;                       // q, k, v in; o out
-        conv(a.o, bt.att, lvT, bt.y, lvT, ConvOpt());
-        ln(M.ln1[l], bt.x, bt.y, nullptr, bt.x1, lvT, 0, 0);
+        {   // output projection + residual + LayerNorm: one launch (col_layer.hip) where the width is instantiated
+            static const bool no_col = getenv("STS_NO_COL_LAYER") != nullptr;   // experiment knob
+            ColLayerArgs g;
+            memset(&g, 0, sizeof(g));
+            g.x = bt.att; g.x_ld = Ttot; g.wc = a.o.wc; g.bias = a.o.bias;
+            g.add = bt.x; g.add_ld = Ttot; g.g2 = M.ln1[l].g; g.b2 = M.ln1[l].b; g.y = bt.x1; g.y_ld = Ttot; g.C = H;
+            g.seg = lvT.seg; g.B = B; g.max_len = maxT;
+            if (!no_col && conv_mode != 1 && a.o.Cin == H && a.o.Cout == H && a.o.Cin_pad == H && M.ln1[l].C == H && col_layer_eligible(g)) {
+                flops_[0] += 2.0 * a.o.macs_per_out * (double)Ttot;
+                bytes_[0] += 4.0 * ((double)H * Ttot * 3.0 + (double)H * H);
+                col_layer(g, stream);
+            } else {
+                conv(a.o, bt.att, lvT, bt.y, lvT, ConvOpt());
+                ln(M.ln1[l], bt.x, bt.y, nullptr, bt.x1, lvT, 0, 0);
+            }
+        }
         const DFfn& f = M.ffn[l];
         ConvOpt o1; o1.pad_l = f.ksize == 1 ? 0 : (f.ksize - 1) / 2;
         conv(f.c1, bt.x1, lvT, bt.ffh, lvT, o1);
@@ -346,8 +392,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         ConvOpt op;
         if (ms) { conv(M.sdp_cond, bt.g, lvB, bt.cond_dp, lvB, ConvOpt()); op.ubias = bt.cond_dp; }
         conv(M.sdp_pre, bt.x, lvT, bt.dh, lvT, op);
-        dds(M.sdp_dds, bt.dh, bt.dt1, bt.dt2, lvT);
-        conv(M.sdp_proj, bt.dh, lvT, bt.dc, lvT, ConvOpt());
+        const float* dh = dds(M.sdp_dds, bt.dh, bt.dt1, bt.dt2, lvT);
+        conv(M.sdp_proj, dh, lvT, bt.dc, lvT, ConvOpt());
         HIPCK(hipMemsetAsync(bt.dr[0], 0, (size_t)2 * ((Ttot * 4 + 255) / 256 * 256), stream));   // dr[0], dr[1] are adjacent
         float *r0 = bt.dr[0], *r1 = bt.dr[1], *n0 = bt.dr[2], *n1 = bt.dr[3];
         for (int i = M.sdp_flows - 1; i > 0; i--) {   // flow 0 is skipped; z == 0 because noise_scale == 0
@@ -355,8 +401,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
             Lvl l1 = lvT;
             ConvOpt oa; oa.epi = EPI_RESADD; oa.res = bt.dc;   // DDSConv(x + g): the "+ g" rides on the pre conv
             conv(cf.pre, r0, l1, bt.dhh, lvT, oa);
-            dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT);
-            conv(cf.proj, bt.dhh, lvT, bt.dp29, lvT, ConvOpt());
+            const float* dhh = dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT);
+            conv(cf.proj, dhh, lvT, bt.dp29, lvT, ConvOpt());
             spline_step(bt.dp29, Ttot, sqrtf((float)cf.filter), r0, r1, n0, n1, Ttot, stream);
             float* t;
             t = r0; r0 = n0; n0 = t;
@@ -436,7 +482,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     if (!ensure(arenaF_, arenaF_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (frame-level workspace)");
     arenaF_.measuring = false; layoutF(arenaF_);
 
-    Lvl lv1; lv1.seg = SegView{d_offF, d_lenF, 1, 0}; lv1.nb = B; lv1.max_len = maxF; lv1.total = Ftot; lv1.ld = Ftot;
+    Lvl lv1; lv1.seg = inl ? SegView{nullptr, nullptr, 1, 0, 0, p_lenF[0]} : SegView{d_offF, d_lenF, 1, 0, 0, 0};
+    lv1.nb = B; lv1.max_len = maxF; lv1.total = Ftot; lv1.ld = Ftot;
     mark(7);
     // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
     stage_begin(2);
@@ -472,13 +519,17 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     // utterances and zoff == coff == offF.)  d_win = device ints {zoff[nw], coff[nw], wlen[nw]}.
     stage_begin(3);
     int* const d_win = bt.meta_i + 5 * B + 2;
-    auto decode = [&](int nw, long Wtot, int maxW) -> int {
+    // (zoff0 = frame offset of window 0 inside z: the by-value form of a single window)
+    auto decode = [&](int nw, long Wtot, int maxW, int zoff0) -> int {
+    const bool winl = nw == 1 && !no_inline_seg;
     auto lvF = [&](int scale, int extra) {
-        Lvl l; l.seg = SegView{d_win + nw, d_win + 2 * nw, scale, extra}; l.nb = nw; l.max_len = maxW * scale + extra;
+        Lvl l; l.seg = winl ? SegView{nullptr, nullptr, scale, extra, 0, maxW} : SegView{d_win + nw, d_win + 2 * nw, scale, extra, 0, 0};
+        l.nb = nw; l.max_len = maxW * scale + extra;
         l.total = Wtot * scale + (long)nw * extra; l.ld = l.total;
         return l;
     };
-    Lvl lz; lz.seg = SegView{d_win, d_win + 2 * nw, 1, 0}; lz.nb = nw; lz.max_len = maxW; lz.total = Ftot; lz.ld = Ftot;
+    Lvl lz; lz.seg = winl ? SegView{nullptr, nullptr, 1, 0, zoff0, maxW} : SegView{d_win, d_win + 2 * nw, 1, 0, 0, 0};
+    lz.nb = nw; lz.max_len = maxW; lz.total = Ftot; lz.ld = Ftot;
     const Lvl lw1 = lvF(1, 0);
     {
         ConvOpt op;
@@ -664,7 +715,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     n_samples.resize(B);
     for (int b = 0; b < B; b++) n_samples[b] = p_lenF[b] * hop;
     if (!ss) {
-        const int rc = decode(B, Ftot, maxF);   // windows = utterances (uploaded with the frame geometry)
+        const int rc = decode(B, Ftot, maxF, 0);   // windows = utterances (uploaded with the frame geometry)
         if (rc != STS_OK) return rc;
         d_pcm = bf.pcm;
         total_samples = Ftot * hop;
@@ -688,7 +739,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
             const long w0 = std::max<long>(0, f0 - halo), w1 = std::min<long>(F, f1 + halo);
             pw[0] = (int)w0; pw[1] = 0; pw[2] = (int)(w1 - w0);
             HIPCK(hipMemcpyAsync(d_win, pw, 3 * 4, hipMemcpyHostToDevice, stream));
-            const int rc = decode(1, w1 - w0, (int)(w1 - w0));
+            const int rc = decode(1, w1 - w0, (int)(w1 - w0), (int)w0);
             if (rc != STS_OK) return rc;
             const long ns = (f1 - f0) * hop;
             HIPCK(hipMemcpyAsync(hp, bf.pcm + (f0 - w0) * hop, (size_t)ns * 2, hipMemcpyDeviceToHost, stream));

@@ -77,7 +77,7 @@ private:
     void conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o);
     void ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu, int nb = 1, long b_stride = 0);
     int pick_kslices(const DConv& c, const Lvl& lout) const;
-    void dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv);
+    float* dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv);
     void tap(const char* name, const float* d, int channels, long ld, long length);
     void stage_begin(int s);
     void mark(int i);

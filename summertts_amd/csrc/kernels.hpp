@@ -13,11 +13,15 @@ namespace sts {
 // Utterance b occupies positions [off[b]*scale + b*extra, ... + len[b]*scale + extra) of a packed row.
 // off/len are in "base units" (phonemes for the text-side buffers, frames for the acoustic side);
 // scale is the upsampling factor accumulated so far; extra is 1 for the MB-iSTFT tail (frames+1 rows).
+// A single-segment view may carry its geometry BY VALUE (off == nullptr: the one segment is {ioff, ilen}): for the
+// reference's own call shape -- one utterance per infer() -- every kernel then starts without the dependent scalar load
+// of its segment table (one memory round trip less on each of the ~140 latency-bound launches of a batch-1 step).
 struct SegView {
     const int* off;
     const int* len;
     int scale;
     int extra;
+    int ioff, ilen;
 };
 
 enum Epilogue : int {
@@ -81,6 +85,26 @@ struct LnArgs {
     const float* dw_w; const float* dw_b; int dw_k, dw_dil, dw_pad, dw_ld;
     SegView seg; int B, max_len;
 };
+
+// Fused column-block layer (col_layer.hip): [depthwise conv + LayerNorm + GELU] -> 1x1 conv (C -> C) -> (+ add) ->
+// LayerNorm -> [GELU] -> [+ res], one workgroup per 16 time steps, all C channels.
+struct ColLayerArgs {
+    const float* x; long x_ld;                  // input [C][ld]
+    const float* dw_w; const float* dw_b; int dw_k, dw_dil, dw_pad, dw_ld;   // optional depthwise conv (null: plain input)
+    const float* g1; const float* b1;           // LayerNorm after the depthwise conv (followed by GELU)
+    const float* wc; const float* bias;         // 1x1 conv weights in the kernel's own A-strip order (col_layer_pack)
+    const float* add; long add_ld;              // v = add + conv(..)   (null: v = conv(..))
+    const float* g2; const float* b2; int post_gelu;
+    const float* res; long res_ld;              // out = res + f(v)
+    float* y; long y_ld;
+    int C;
+    SegView seg; int B, max_len;
+};
+bool col_layer_eligible(const ColLayerArgs& a);
+bool col_layer_width_ok(int C);
+// w: [C out][C in] (blob order of a 1x1 conv) -> dst[C * C] in col_layer_kernel's A-strip order
+void col_layer_pack(const float* w, int C, float* dst);
+void col_layer(const ColLayerArgs& a, hipStream_t st);
 
 struct AttnArgs {
     const float* q; const float* k; const float* v; float* o; long ld;

@@ -7,8 +7,8 @@
 
 namespace sts {
 
-__device__ __forceinline__ int seg_start(const SegView& s, int b) { return s.off[b] * s.scale + b * s.extra; }
-__device__ __forceinline__ int seg_len(const SegView& s, int b) { return s.len[b] * s.scale + s.extra; }
+__device__ __forceinline__ int seg_start(const SegView& s, int b) { return (s.off ? s.off[b] : s.ioff) * s.scale + b * s.extra; }
+__device__ __forceinline__ int seg_len(const SegView& s, int b) { return (s.off ? s.len[b] : s.ilen) * s.scale + s.extra; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -62,9 +62,17 @@ __device__ __forceinline__ float ln_input(const LnArgs& a, int c, size_t p, int 
         v = a.a[(size_t)c * a.a_ld + p];
     }
     if (a.b) {
-        float bs = a.b[(size_t)c * a.b_ld + p];
-        for (int q = 1; q < a.nb; q++) bs += a.b[(size_t)q * a.b_stride + (size_t)c * a.b_ld + p];   // split-K partials, fixed order
-        v += bs;
+        if (a.nb > 1) {     // split-K partials: all loads issued together, summed in a fixed order (slices beyond nb add +0)
+            float pb[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) pb[q] = q < a.nb ? a.b[(size_t)q * a.b_stride + (size_t)c * a.b_ld + p] : 0.f;
+            float bs = pb[0];
+#pragma unroll
+            for (int q = 1; q < 8; q++) bs += pb[q];
+            v += bs;
+        } else {
+            v += a.b[(size_t)c * a.b_ld + p];
+        }
     }
     if (a.pre_relu && v < 0.f) v = 0.f;
     return v;

@@ -134,6 +134,15 @@ bool pack_wino(Store& st, const HConv& h, DConv& d) {
     return true;
 }
 
+// extra copy of a square 1x1 conv in the fused column-block kernel's operand order (col_layer.hip)
+bool pack_col(Store& st, const HConv& h, DConv& d) {
+    if (h.k != 1 || h.in_ch != h.out_ch || d.depthwise || !col_layer_width_ok(h.in_ch)) return true;
+    float* p = st.alloc((size_t)h.in_ch * h.in_ch, &d.wc);
+    if (!p) { d.wc = nullptr; return false; }
+    col_layer_pack(h.w, h.in_ch, p);
+    return true;
+}
+
 // polyphase repack of a transposed conv: phase p holds taps k = p + j*stride
 bool pack_convT(Store& st, const HConv& h, int stride, int pad, DConv& d) {
     d = DConv();
@@ -188,7 +197,7 @@ bool parse_pack_dds(Reader& r, Store& st, DDds& d) {
         if (!pack_conv(st, h, o, d.sep[i])) return false;
         dil *= k;
     }
-    for (int i = 0; i < d.n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), d.pw[i])) return false; }
+    for (int i = 0; i < d.n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), d.pw[i]) || !pack_col(st, h, d.pw[i])) return false; }
     for (int i = 0; i < d.n; i++) { HLn h = parse_ln(r); if (!r.ok || !pack_ln(st, h, d.n1[i])) return false; }
     for (int i = 0; i < d.n; i++) { HLn h = parse_ln(r); if (!r.ok || !pack_ln(st, h, d.n2[i])) return false; }
     return true;
@@ -284,7 +293,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         }
         HConv cat; cat.out_ch = 3 * a.ch; cat.in_ch = a.ch; cat.k = 1; cat.pad = 0; cat.dil = 1; cat.has_bias = anyb ? 1 : 0;
         cat.w = wcat.data(); cat.b = bcat.data();
-        if (!pack_conv(st, cat, PackOpts(), a.qkv) || !pack_conv(st, o, PackOpts(), a.o)) FAIL("weight store overflow");
+        if (!pack_conv(st, cat, PackOpts(), a.qkv) || !pack_conv(st, o, PackOpts(), a.o) || !pack_col(st, o, a.o)) FAIL("weight store overflow");
     }
     for (int i = 0; i < m.n_layers; i++) { HLn h = parse_ln(r); if (!r.ok || !pack_ln(st, h, m.ln1[i])) FAIL("ln1"); }
     for (int i = 0; i < m.n_layers; i++) {   // /root/reference/src/modules/ffn.cpp:27-30

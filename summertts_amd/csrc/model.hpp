@@ -30,6 +30,7 @@ struct DConv {
     int gate_perm = 0, H = 0;
     const float* w = nullptr;
     const float* bias = nullptr;
+    const float* wc = nullptr;      // col_layer_kernel's A-strip copy of a square 1x1 conv (DDSConv pointwise convs, attention o-proj)
     const float* wu = nullptr;      // Winograd-domain copy [seg][4][Cin_pad][Cout_pad] (narrow decoder ResBlock convs)
     double macs_per_out = 0;   // true-tap MACs per output position (all output channels)
 };
