@@ -1418,7 +1418,11 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
         const TileCfg& t = kTiles[tile];
         const int MT = 32 * t.MW * t.WM, NT = 32 * t.NW * t.WN;
         const long blocks = (long)((a.max_n + NT - 1) / NT) * ((a.Cout_pad + MT - 1) / MT) * nphase * a.B;
-        if (blocks < 256 && (double)a.Cin_pad * (double)a.x_ld * 4.0 < 2.0e9) { splitk = true; nw = ((a.max_n + 63) / 64) * ((a.Cout_pad + 31) / 32) * nphase * (long)a.B >= 512 ? 2 : 1; }
+        const bool fits32 = (double)a.Cin_pad * (double)a.x_ld * 4.0 < 2.0e9;    // split-K folds the rows into a 32-bit buffer offset
+        if (blocks < 256 && fits32) { splitk = true; nw = ((a.max_n + 63) / 64) * ((a.Cout_pad + 31) / 32) * nphase * (long)a.B >= 512 ? 2 : 1; }
+        // a short, K-heavy transposed conv (HiFi-GAN's first upsampler at one utterance: 669 positions, K = 2 x 512) leaves the
+        // LDS-staged grid at ~3 long workgroups per CU; split over waves it runs 84 -> 51 us (profiles/r01_conv_microbench.log)
+        else if (a.transposed && blocks < 1024 && (long)a.ntap * (a.Cin_pad / 8) >= 128 && fits32) { splitk = true; nw = 2; }
     }
     if (splitk) {
         if (nw == 2) launch_splitk<1, 2>(a, nphase, st); else launch_splitk<1, 1>(a, nphase, st);

@@ -574,6 +574,22 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
             // few hundred), and chains of different kernel size backfill each other inside the grid.
             const float* cur[kMaxGroup];
             for (int j = 0; j < nk; j++) cur[j] = bup;
+            // experiment knob STS_CHAIN_STREAMS=<stage mask>: the chains of the masked stages go out as per-chain launches on
+            // the prioritised auxiliary streams (heaviest chain first) instead of one grouped launch per layer
+            static const int chain_streams = getenv("STS_CHAIN_STREAMS") ? atoi(getenv("STS_CHAIN_STREAMS")) : 0;
+            const bool per_chain = ((chain_streams >> i) & 1) && nk <= kAux;
+            int crank[kMaxGroup];
+            for (int j = 0; j < nk; j++) {
+                crank[j] = 0;
+                for (int q = 0; q < nk; q++) {
+                    const int kj = M.rb[(size_t)i * nk + j].c1[0].k, kq = M.rb[(size_t)i * nk + q].c1[0].k;
+                    if (kq < kj || (kq == kj && q < j)) crank[j]++;
+                }
+            }
+            if (per_chain) {
+                (void)hipEventRecord(ev_fork_, stream);
+                for (int k = 0; k < kAux; k++) (void)hipStreamWaitEvent(aux_[k], ev_fork_, 0);
+            }
             static const bool no_fuse = getenv("STS_NO_FUSE") != nullptr;   // experiment knob
             for (int d = 0; d < nd0; d++) {
                 // narrow stages: the whole layer (conv1 -> lrelu -> conv2 -> + x) of all chains in one launch
@@ -611,7 +627,12 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     // the direct-form fused kernel otherwise
                     static const bool no_wino = getenv("STS_NO_WINO") != nullptr;   // experiment knob
                     const bool wino = !no_wino && resblock_wino_eligible(R);
-                    if (wino) resblock_wino(R, stream);
+                    if (per_chain) {
+                        for (int j = 0; j < nk; j++) {
+                            ResLayerGroup R1 = R; R1.n = 1; R1.g[0] = R.g[j];
+                            if (wino) resblock_wino(R1, aux_[crank[j] % kAux]); else resblock_layer(R1, aux_[crank[j] % kAux]);
+                        }
+                    } else if (wino) resblock_wino(R, stream);
                     else resblock_layer(R, stream);
                     mfma_flops_ += fl; mfma_exec_ += wino ? flw : fl; mfma_launches_ += 1;
                     continue;
@@ -632,12 +653,23 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 const int gtile = gt && (int)strlen(gt) > i ? gt[i] - '0' : -1;
                 // every layer is checked on its own: later layers have larger dilations, and a halo beyond the staged
                 // LDS window (e.g. k = 11 with dilation 7) must take the per-conv path, which falls back to conv_generic
+                if (per_chain) {
+                    for (int j = 0; j < nk; j++) {
+                        hipStream_t cs = aux_[crank[j] % kAux];
+                        if (conv_mfma_eligible(G1.g[j])) conv_mfma(G1.g[j], cs, gtile); else conv_generic(G1.g[j], cs);
+                        if (conv_mfma_eligible(G2.g[j])) conv_mfma(G2.g[j], cs, gtile); else conv_generic(G2.g[j], cs);
+                    }
+                    mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
+                    continue;
+                }
                 if (conv_group_eligible(G1)) conv_mfma_group(G1, stream, gtile);
                 else for (int j = 0; j < nk; j++) { if (conv_mfma_eligible(G1.g[j])) conv_mfma(G1.g[j], stream, -1); else conv_generic(G1.g[j], stream); }
                 if (conv_group_eligible(G2)) conv_mfma_group(G2, stream, gtile);
                 else for (int j = 0; j < nk; j++) { if (conv_mfma_eligible(G2.g[j])) conv_mfma(G2.g[j], stream, -1); else conv_generic(G2.g[j], stream); }
                 mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
             }
+            if (per_chain)
+                for (int k = 0; k < kAux; k++) { (void)hipEventRecord(ev_join_[k], aux_[k]); (void)hipStreamWaitEvent(stream, ev_join_[k], 0); }
             for (int j = 0; j < nk; j++) outs[j] = cur[j];
         } else {
             // fallback: the chains run concurrently on separate HIP streams

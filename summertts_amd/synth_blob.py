@@ -386,6 +386,78 @@ def make_blob(cfg: ModelCfg, seed: int = 1234) -> np.ndarray:
     return w.blob()
 
 
+ENG_IPA_SYMBOLS = 178     # len(ipaSymbols_) in /root/reference/src/engipa/EnglishText2Id.cpp:65: the id range of the English frontend
+ENG_G2P_PHONES = 74       # id2Phone_ entries (EnglishText2Id.cpp:161-234)
+
+
+def eng_frontend_section(seed: int = 7, hidden: int = 24) -> np.ndarray:
+    """The frontend section that follows the acoustic sections of an ENGLISH model blob (lang = 1): the twelve matrices of the
+    g2p GRU seq2seq fallback, in the order /root/reference/src/engipa/EnglishText2Id.cpp:74-131 reads them (matrices carry
+    [rows, cols] headers, biases [n]; Eigen column-major; embedding width == hidden width, required by gru() :294-306).
+    Random weights: dictionary words never touch them (the 125 k-word table is compiled into the frontend), only
+    out-of-vocabulary words of >= 4 letters do."""
+    w = _W(seed)
+    h = hidden
+
+    def mat(r, c):
+        w.ints(r, c)
+        w.arr(w.normal((c, r), 0.3))
+
+    def vec(n):
+        w.ints(n)
+        w.arr(w.normal((n,), 0.1))
+
+    mat(29, h); mat(3 * h, h); mat(3 * h, h); vec(3 * h); vec(3 * h)          # encoder: emb, w_ih, w_hh, b_ih, b_hh
+    mat(ENG_G2P_PHONES, h); mat(3 * h, h); mat(3 * h, h); vec(3 * h); vec(3 * h)   # decoder
+    mat(ENG_G2P_PHONES, h); vec(ENG_G2P_PHONES)                               # fc
+    return w.blob()
+
+
+def chs_frontend_sections(tagger: bytes, verbalizer: bytes, jieba: Sequence[bytes], poly_words: bytes, poly_pinyin: bytes,
+                          float_offset: int) -> Tuple[np.ndarray, dict]:
+    """The three frontend sections of a CHINESE model blob as /root/reference/src/models/SynthesizerTrn.cpp:181-297 walks
+    them: [tagger size, verbalizer size, bytes...] [5 jieba sizes, bytes...] [2 polyphone sizes, bytes...], each section
+    followed by the reference's alignment step  off_char += off_char % 4  (NOT a round-up: remainder 1 -> +1, 3 -> +3),
+    then off = off_char / 4.  float_offset = float index at which the first section starts (the acoustic sections' end).
+    Returns (float32 array to append, {section: float offset of its payload, 'end': float offset after the walk})."""
+    out = bytearray()
+    info = {}
+
+    def cur_float():
+        return float_offset + len(out) // 4
+
+    def put_ints(*v):
+        out.extend(np.asarray(v, np.float32).tobytes())
+
+    def put_payload(chunks):
+        start_char = float_offset * 4 + len(out)
+        tot = sum(len(c) for c in chunks)
+        for c in chunks:
+            out.extend(c)
+        off_char = start_char + tot
+        if off_char % 4 > 0:
+            off_char += off_char % 4
+        nxt = off_char // 4                                      # where the reference continues reading floats
+        need = nxt * 4 - (float_offset * 4 + len(out))
+        if need > 0:
+            out.extend(b"\0" * need)
+        elif need < 0:                                           # the walk lands INSIDE the payload's last float: pad to it
+            out.extend(b"\0" * ((-need) % 4))
+        while len(out) % 4:
+            out.extend(b"\0")
+        return nxt
+
+    put_ints(len(tagger), len(verbalizer)); info["tn"] = cur_float()
+    nxt = put_payload([tagger, verbalizer]); info["after_tn"] = nxt
+    assert nxt == cur_float(), "synthetic sizes must keep the walk on the written stream"
+    put_ints(*[len(c) for c in jieba]); info["jieba"] = cur_float()
+    nxt = put_payload(list(jieba)); info["after_jieba"] = nxt
+    assert nxt == cur_float()
+    put_ints(len(poly_words), len(poly_pinyin)); info["poly"] = cur_float()
+    nxt = put_payload([poly_words, poly_pinyin]); info["end"] = nxt
+    return np.frombuffer(bytes(out), dtype=np.float32).copy(), info
+
+
 def synthetic_ids(n: int, vocab: int, salt: int = 0) -> np.ndarray:
     """Fixed seeded phoneme-id sequence: ids[i] = (i*37 + 11 + salt) mod vocab."""
     i = np.arange(n, dtype=np.int64)
