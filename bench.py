@@ -225,6 +225,8 @@ def main():
     blob = sb.make_blob(cfg, 1234)
     syn = eng.Synthesizer(blob, device=dev_index)
     syn.set_conv_mode(args.conv_mode)
+    if dist is not None and args.backend == "nccl" and hasattr(syn, "set_host_pcm"):
+        syn.set_host_pcm(False)          # the PCM goes device-to-device into the RCCL gather
 
     # global batch = world * batch utterances, sharded by utterance (no data-path collective)
     gB = world * args.batch

@@ -85,6 +85,10 @@ int sts_infer_ids_batch(sts_engine* e, int32_t B, const int32_t* const* ids, con
  * sts_copy_pcm_device (device-to-device, asynchronous on the engine stream then synchronised). */
 int sts_run_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int32_t* n, const int32_t* sid,
                   const float* length_scale, int32_t* n_out, int64_t* total_out);
+/* sts_set_host_pcm(e, 1): sts_run_batch also downloads the PCM into an engine-owned pinned host buffer as the last step of
+ * the run (one stream synchronisation per call instead of two); sts_copy_pcm_host then copies from that buffer.  Leave it
+ * off (default) when the PCM stays on the device for an RCCL gather. */
+int sts_set_host_pcm(sts_engine* e, int enable);
 int sts_copy_pcm_device(sts_engine* e, void* device_dst, int64_t capacity_samples);
 int sts_copy_pcm_host(sts_engine* e, int16_t* host_dst, int64_t capacity_samples);
 

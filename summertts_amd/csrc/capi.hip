@@ -70,6 +70,7 @@ int sts_copy_pcm_device(sts_engine* e, void* dst, int64_t cap) {
 int sts_copy_pcm_host(sts_engine* e, int16_t* dst, int64_t cap) {
     if (!e || !dst) return set_err(STS_EINVAL, "null argument");
     if (cap < e->eng.total_samples || !e->eng.d_pcm) return set_err(STS_ESTATE, "destination too small or no run yet");
+    if (e->eng.h_pcm) { memcpy(dst, e->eng.h_pcm, (size_t)e->eng.total_samples * 2); return STS_OK; }   // downloaded inside the run
     if (hipMemcpyAsync(dst, e->eng.d_pcm, (size_t)e->eng.total_samples * 2, hipMemcpyDeviceToHost, e->eng.stream) != hipSuccess ||
         hipStreamSynchronize(e->eng.stream) != hipSuccess)
         return set_err(STS_EDEVICE, "device-to-host copy failed");
@@ -80,7 +81,11 @@ int sts_infer_ids_batch(sts_engine* e, int32_t B, const int32_t* const* ids, con
                         const float* length_scale, int16_t** pcm_out, int32_t* n_out) {
     if (!pcm_out || !n_out) return set_err(STS_EINVAL, "null output");
     int64_t total = 0;
+    if (!e) return set_err(STS_EINVAL, "null engine");
+    const bool was = e->eng.host_pcm;
+    e->eng.host_pcm = true;               // the PCM download rides at the end of the run: one stream sync for the whole call
     int rc = sts_run_batch(e, B, ids, n, sid, length_scale, n_out, &total);
+    e->eng.host_pcm = was;
     if (rc != STS_OK) return rc;
     int16_t* all = (int16_t*)malloc((size_t)(total > 0 ? total : 1) * 2);
     if (!all) return set_err(STS_EDEVICE, "out of host memory");
@@ -134,6 +139,7 @@ int sts_set_forced_durations(sts_engine* e, const int32_t* dur, int64_t count) {
 
 int sts_set_record_taps(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.record_taps = enable != 0; return STS_OK; }
 int sts_set_conv_mode(sts_engine* e, int mode) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.conv_mode = mode; return STS_OK; }
+int sts_set_host_pcm(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.host_pcm = enable != 0; return STS_OK; }
 int sts_set_profiling(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.profiling = enable != 0; return STS_OK; }
 
 int sts_get_profile(const sts_engine* e, sts_profile* p) {

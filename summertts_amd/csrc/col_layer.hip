@@ -51,18 +51,29 @@ __global__ __launch_bounds__(64 * NSUB) void col_layer_kernel(ColLayerArgs a) {
     // stage's taps first, then the wave's A strip and the epilogue operands, which land under the input stage's VALU work
     float xin[4][3], dww[4][3], dwb[4], g1[4], b1[4];
     if (a.dw_w) {
+        float xrq[3] = {0.f, 0.f, 0.f};          // rank-1 input term: the 1 -> C conv of the flow input, evaluated at the three taps
+        if (a.xs_w && a.xr) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int q = pos + j * a.dw_dil - a.dw_pad;
+                if (live && j < a.dw_k && q >= 0 && q < len) xrq[j] = a.xr[base + q];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int c = cg + i * CG;
             const float* row = a.x + (size_t)c * a.x_ld + base;
             g1[i] = a.g1[c]; b1[i] = a.b1[c];
             dwb[i] = a.dw_b ? a.dw_b[c] : 0.f;
+            const float sw = a.xs_w ? a.xs_w[c] : 0.f, sb = (a.xs_w && a.xs_b) ? a.xs_b[c] : 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) {        // dw_k <= 3 here (col_layer_eligible); absent taps carry weight 0
                 const int q = pos + j * a.dw_dil - a.dw_pad;
                 const bool ok = live && j < a.dw_k && q >= 0 && q < len && !(STS_EXP & 8);
                 dww[i][j] = j < a.dw_k ? a.dw_w[(size_t)j * a.dw_ld + c] : 0.f;
-                xin[i][j] = ok ? row[q] : 0.f;
+                float xv = ok ? row[q] : 0.f;
+                if (a.xs_w && ok) xv = __fadd_rn(__fadd_rn(__fmul_rn(sw, xrq[j]), sb), xv);   // (w x + b) + g, rounded as the separate conv did
+                xin[i][j] = xv;
             }
         }
     } else {
@@ -85,6 +96,10 @@ __global__ __launch_bounds__(64 * NSUB) void col_layer_kernel(ColLayerArgs a) {
         e_g[r] = a.g2[row0 + r]; e_b[r] = a.b2[row0 + r];
         e_add[r] = (a.add && live) ? a.add[(size_t)(row0 + r) * a.add_ld + base + pos] : 0.f;
         e_res[r] = (a.res && live) ? a.res[(size_t)(row0 + r) * a.res_ld + base + pos] : 0.f;
+        if (a.xs_w && a.res && live) {           // the residual is the same folded input h
+            const float xr0 = a.xr ? a.xr[base + pos] : 0.f;
+            e_res[r] = __fadd_rn(__fadd_rn(__fmul_rn(a.xs_w[row0 + r], xr0), a.xs_b ? a.xs_b[row0 + r] : 0.f), e_res[r]);
+        }
     }
 
     // ---- 2. input stage
@@ -181,6 +196,7 @@ bool col_layer_eligible(const ColLayerArgs& a) {
     if (!col_layer_width_ok(a.C)) return false;
     if (!a.wc || !a.g2 || !a.b2 || !a.x || !a.y) return false;
     if (a.dw_w && (!a.g1 || !a.b1 || a.dw_k < 1 || a.dw_k > 3)) return false;
+    if (a.xs_w && (!a.dw_w || a.res != a.x)) return false;     // the folded input is defined for the DDSConv form only
     if (a.y == a.x) return false;               // other workgroups read x (halo of the depthwise conv) while this one writes y
     return a.max_len > 0 && a.B > 0;
 }

@@ -26,6 +26,7 @@ Engine::~Engine() {
     if (arenaT_.base) (void)hipFree(arenaT_.base);
     if (arenaF_.base) (void)hipFree(arenaF_.base);
     if (pinned_) (void)hipHostFree(pinned_);
+    if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
     if (have_events_) {
         for (auto& e : ev_) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_fork_);
@@ -159,9 +160,21 @@ void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, 
 
 // /root/reference/src/modules/DDSConv.cpp:84-111: x += gelu(LN2(conv1x1(gelu(LN1(dwconv(x))))))
 // Returns the buffer that holds the result (h or t1: the fused layers ping-pong between them).
-float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv) {
+// `pre` (optional): the ConvFlow's 1 -> C input conv, h = (pre(pre_in) + pre_res) (/root/reference/src/modules/ConvFlow.cpp:252-254;
+// pre_in == null: the all-zero latent).  Where the first layer runs fused, h is never materialised: the kernel evaluates it at its
+// depthwise taps; otherwise the conv runs first, into `h`.
+float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre, const float* pre_in, const float* pre_res) {
     static const bool no_col = getenv("STS_NO_COL_LAYER") != nullptr;   // experiment knob
     float* cur = h;
+    bool pre_pending = pre != nullptr;
+    auto run_pre = [&]() {      // the unfused form of the input conv (zero input: a memset feeds it)
+        if (!pre_pending) return;
+        pre_pending = false;
+        const float* in = pre_in;
+        if (!in) { (void)hipMemsetAsync(t2, 0, (size_t)lv.total * sizeof(float), cur_); in = t2; }
+        ConvOpt oa; oa.epi = EPI_RESADD; oa.res = pre_res;
+        conv(*pre, in, lv, h, lv, oa);
+    };
     for (int i = 0; i < d.n; i++) {
         const DConv& c = d.sep[i];
         const DConv& pw = d.pw[i];
@@ -179,6 +192,15 @@ float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv)
             g.g2 = d.n2[i].g; g.b2 = d.n2[i].b; g.post_gelu = 1;
             g.res = cur; g.res_ld = lv.ld; g.y = nxt; g.y_ld = lv.ld; g.C = pw.Cin;
             g.seg = lv.seg; g.B = lv.nb; g.max_len = lv.max_len;
+            if (pre_pending && i == 0 && pre->Cin == 1 && pre->k == 1 && pre->Cout == pw.Cin && !pre->depthwise && pre_res) {
+                // fold h = (w r + b) + g into the layer: x = res = g, rank-1 term from the conv's single input row
+                g.x = pre_res; g.res = pre_res; g.xs_w = pre->w; g.xs_b = pre->bias; g.xr = pre_in;
+                if (col_layer_eligible(g)) {
+                    pre_pending = false;
+                    flops_[cur_stage_] += 2.0 * pre->macs_per_out * (double)lv.total;
+                } else { g.x = cur; g.res = cur; g.xs_w = g.xs_b = g.xr = nullptr; }
+            }
+            run_pre();
             if (col_layer_eligible(g)) {
                 flops_[cur_stage_] += 2.0 * (c.macs_per_out + pw.macs_per_out) * (double)lv.total;
                 bytes_[cur_stage_] += 4.0 * ((double)pw.Cin * lv.total * 2.0 + (double)pw.Cin * pw.Cout);
@@ -187,6 +209,7 @@ float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv)
                 continue;
             }
         }
+        run_pre();
         {   // depthwise conv fused into the LayerNorm that consumes it (one launch instead of two)
             LnArgs g;
             memset(&g, 0, sizeof(g));
@@ -284,10 +307,12 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     BufT bt;
     auto layoutT = [&](Arena& A) {
         A.used = 0;
-        bt.meta_i = A.get<int>((size_t)9 * B + 8);
-        bt.ls = A.get<float>(B);
-        bt.ids = A.get<int>(Ttot);
-        bt.forced = A.get<int>(Ttot);
+        // one device block mirroring the pinned staging block [geometry ints | length scales | ids | forced durations]:
+        // a single host-to-device copy per run
+        bt.meta_i = A.get<int>((size_t)9 * B + 8 + B + 2 * (size_t)Ttot);
+        bt.ls = (float*)(bt.meta_i + ((size_t)9 * B + 8));
+        bt.ids = (int*)(bt.ls + B);
+        bt.forced = bt.ids + Ttot;
         bt.x = A.get<float>((size_t)H * Ttot); bt.qkv = A.get<float>((size_t)3 * H * Ttot);
         bt.att = A.get<float>((size_t)H * Ttot); bt.y = A.get<float>((size_t)H * Ttot * ffn2_slices);
         bt.x1 = A.get<float>((size_t)H * Ttot); bt.ffh = A.get<float>((size_t)FF * Ttot);
@@ -324,10 +349,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     for (int b = 0; b < B; b++) memcpy(p_ids + offT[b], ids[b], sizeof(int) * n[b]);
     int* p_forced = p_ids + Ttot;
     if (have_forced) memcpy(p_forced, forced_dur.data(), sizeof(int) * Ttot);
-    HIPCK(hipMemcpyAsync(bt.meta_i, pm, meta_ints * 4, hipMemcpyHostToDevice, stream));
-    HIPCK(hipMemcpyAsync(bt.ls, p_ls, (size_t)B * 4, hipMemcpyHostToDevice, stream));
-    HIPCK(hipMemcpyAsync(bt.ids, p_ids, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
-    if (have_forced) HIPCK(hipMemcpyAsync(bt.forced, p_forced, (size_t)Ttot * 4, hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemcpyAsync(bt.meta_i, pm, (meta_ints + B + (size_t)Ttot * (have_forced ? 2 : 1)) * 4, hipMemcpyHostToDevice, stream));
 
     // single-segment views travel by value (kernels.hpp SegView): no segment-table load in the kernels of a one-utterance call
     static const bool no_inline_seg = getenv("STS_NO_INLINE_SEG") != nullptr;   // experiment knob
@@ -394,19 +416,20 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         conv(M.sdp_pre, bt.x, lvT, bt.dh, lvT, op);
         const float* dh = dds(M.sdp_dds, bt.dh, bt.dt1, bt.dt2, lvT);
         conv(M.sdp_proj, dh, lvT, bt.dc, lvT, ConvOpt());
-        HIPCK(hipMemsetAsync(bt.dr[0], 0, (size_t)2 * ((Ttot * 4 + 255) / 256 * 256), stream));   // dr[0], dr[1] are adjacent
-        float *r0 = bt.dr[0], *r1 = bt.dr[1], *n0 = bt.dr[2], *n1 = bt.dr[3];
+        // the latent z starts as zeros (noise scale 0, StochasticDurationPredictor.cpp:129-131): null inputs stand for it
+        const float *r0 = nullptr, *r1 = nullptr;
+        float *n0 = bt.dr[2], *n1 = bt.dr[3], *s0 = bt.dr[0], *s1 = bt.dr[1];
+        if (M.sdp_flows <= 1) { HIPCK(hipMemsetAsync(bt.dr[0], 0, (size_t)Ttot * 4, stream)); r0 = bt.dr[0]; }
         for (int i = M.sdp_flows - 1; i > 0; i--) {   // flow 0 is skipped; z == 0 because noise_scale == 0
             const DConvFlow& cf = M.cf[i];
-            Lvl l1 = lvT;
-            ConvOpt oa; oa.epi = EPI_RESADD; oa.res = bt.dc;   // DDSConv(x + g): the "+ g" rides on the pre conv
-            conv(cf.pre, r0, l1, bt.dhh, lvT, oa);
-            const float* dhh = dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT);
+            // DDSConv(pre(x0) + g): the 1 -> C input conv and the "+ g" ride inside the first DDSConv layer
+            const float* dhh = dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT, &cf.pre, r0, bt.dc);
             conv(cf.proj, dhh, lvT, bt.dp29, lvT, ConvOpt());
             spline_step(bt.dp29, Ttot, sqrtf((float)cf.filter), r0, r1, n0, n1, Ttot, stream);
+            r0 = n0; r1 = n1;
             float* t;
-            t = r0; r0 = n0; n0 = t;
-            t = r1; r1 = n1; n1 = t;
+            t = n0; n0 = s0; s0 = t;
+            t = n1; n1 = s1; s1 = t;
         }
         r_final = r0;
     } else {                 // /root/reference/src/models/FixDurationPredictor.cpp:75-96
@@ -448,7 +471,18 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     {   // frame geometry + (normal call) the decode windows = the utterances, in the same copy
         int* pw = pm + 5 * B + 2;
         for (int b = 0; b < B; b++) { pw[b] = p_offF[b]; pw[B + b] = p_offF[b]; pw[2 * B + b] = p_lenF[b]; }
-        HIPCK(hipMemcpyAsync(d_offF, p_offF, (size_t)(5 * B + 2) * 4, hipMemcpyHostToDevice, stream));
+        // (a single utterance carries its geometry in the kernel arguments: nothing on the device reads these tables)
+        if (!inl || ss) HIPCK(hipMemcpyAsync(d_offF, p_offF, (size_t)(5 * B + 2) * 4, hipMemcpyHostToDevice, stream));
+    }
+    h_pcm = nullptr;
+    if (host_pcm && !ss) {   // room for the PCM download that rides at the end of this run
+        const size_t need = (size_t)Ftot * hop * 2 + 256;
+        if (need > pinned_pcm_cap_) {
+            if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
+            pinned_pcm_ = nullptr; pinned_pcm_cap_ = 0;
+            if (hipHostMalloc((void**)&pinned_pcm_, need + need / 2, hipHostMallocDefault) != hipSuccess) return fail(STS_EDEVICE, "pinned host allocation failed");
+            pinned_pcm_cap_ = need + need / 2;
+        }
     }
 
     // ---------------- frame-level workspace.  The flow works on all Ftot frames; the decoder works on
@@ -751,6 +785,10 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         if (rc != STS_OK) return rc;
         d_pcm = bf.pcm;
         total_samples = Ftot * hop;
+        if (host_pcm) {
+            HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)total_samples * 2, hipMemcpyDeviceToHost, stream));
+            h_pcm = (const int16_t*)pinned_pcm_;
+        }
         HIPCK(hipStreamSynchronize(stream));
         HIPCK(hipGetLastError());
     } else {

@@ -60,6 +60,8 @@ public:
     std::vector<int32_t> n_samples;    // per utterance
     int64_t total_samples = 0;
     int16_t* d_pcm = nullptr;          // device, packed
+    const int16_t* h_pcm = nullptr;    // host copy of the last run's PCM (pinned, engine-owned) when host_pcm is set, else null
+    bool host_pcm = false;             // download the PCM as part of run(): one stream sync per call instead of two
     std::vector<int32_t> durations_h;  // packed
     std::map<std::string, Tap> taps;
     sts_profile prof{};
@@ -77,7 +79,8 @@ private:
     void conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o);
     void ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu, int nb = 1, long b_stride = 0);
     int pick_kslices(const DConv& c, const Lvl& lout) const;
-    float* dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv);
+    float* dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre = nullptr, const float* pre_in = nullptr,
+               const float* pre_res = nullptr);
     void tap(const char* name, const float* d, int channels, long ld, long length);
     void stage_begin(int s);
     void mark(int i);
@@ -85,6 +88,7 @@ private:
     std::string err_;
     Arena arenaT_, arenaF_;
     char* pinned_ = nullptr; size_t pinned_cap_ = 0;
+    char* pinned_pcm_ = nullptr; size_t pinned_pcm_cap_ = 0;
     hipEvent_t ev_[8] = {};
     static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently
     hipStream_t aux_[kAux] = {};

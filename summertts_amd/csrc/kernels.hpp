@@ -90,6 +90,9 @@ struct LnArgs {
 // LayerNorm -> [GELU] -> [+ res], one workgroup per 16 time steps, all C channels.
 struct ColLayerArgs {
     const float* x; long x_ld;                  // input [C][ld]
+    // optional rank-1 term of the input: h[c][t] = (xs_w[c] * xr[t] + xs_b[c]) + x[c][t] -- the 1 -> C "pre" conv of a ConvFlow
+    // (/root/reference/src/modules/ConvFlow.cpp:252-254: pre(x0) + g) folded into the first DDSConv layer; xr == null: xr = 0
+    const float* xs_w; const float* xs_b; const float* xr;
     const float* dw_w; const float* dw_b; int dw_k, dw_dil, dw_pad, dw_ld;   // optional depthwise conv (null: plain input)
     const float* g1; const float* b1;           // LayerNorm after the depthwise conv (followed by GELU)
     const float* wc; const float* bias;         // 1x1 conv weights in the kernel's own A-strip order (col_layer_pack)

@@ -376,8 +376,8 @@ __global__ void spline_step_kernel(const float* h, long ld, float fs, const floa
     float hv[29];
 #pragma unroll
     for (int j = 0; j < 29; j++) hv[j] = h[(size_t)j * ld + i];
-    const float a = r0[i];
-    o0[i] = rq_spline_inverse(r1[i], hv, fs);
+    const float a = r0 ? r0[i] : 0.f;             // null inputs = the all-zero latent of the first flow (noise scale 0)
+    o0[i] = rq_spline_inverse(r1 ? r1[i] : 0.f, hv, fs);
     o1[i] = a;
 }
 void spline_step(const float* h, long ld, float filter_sqrt, const float* r0, const float* r1, float* o0, float* o1,

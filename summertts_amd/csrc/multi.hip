@@ -65,8 +65,9 @@ struct sts_multi {
                 if (sh.rc == STS_OK) {
                     sh.n_samples = eng.n_samples;
                     sh.pcm.resize((size_t)std::max<int64_t>(1, eng.total_samples));
-                    if (hipMemcpyAsync(sh.pcm.data(), eng.d_pcm, (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
-                        hipStreamSynchronize(eng.stream) != hipSuccess) { sh.rc = STS_EDEVICE; sh.err = "PCM download failed"; }
+                    if (eng.h_pcm) memcpy(sh.pcm.data(), eng.h_pcm, (size_t)eng.total_samples * 2);   // downloaded inside the run
+                    else if (hipMemcpyAsync(sh.pcm.data(), eng.d_pcm, (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
+                             hipStreamSynchronize(eng.stream) != hipSuccess) { sh.rc = STS_EDEVICE; sh.err = "PCM download failed"; }
                 } else {
                     sh.err = eng.error();
                 }
@@ -112,6 +113,7 @@ int sts_multi_create(const float* blob, int64_t blob_bytes, const int32_t* devic
     if (!m) return multi_err(STS_EDEVICE, "out of host memory");
     for (int k = 0; k < n_devices; k++) {
         m->engines.emplace_back(new Engine());
+        m->engines.back()->host_pcm = true;
         const int rc = m->engines.back()->init(blob, blob_bytes, devices[k]);
         if (rc != STS_OK) { multi_err(rc, "device " + std::to_string(devices[k]) + ": " + m->engines.back()->error()); delete m; return rc; }
     }

@@ -65,8 +65,9 @@ struct sts_pool {
                 std::vector<int16_t> all;
                 if (rc == STS_OK) {
                     all.resize((size_t)(eng.total_samples > 0 ? eng.total_samples : 1));
-                    if (hipMemcpyAsync(all.data(), eng.d_pcm, (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
-                        hipStreamSynchronize(eng.stream) != hipSuccess)
+                    if (eng.h_pcm) memcpy(all.data(), eng.h_pcm, (size_t)eng.total_samples * 2);   // downloaded inside the run
+                    else if (hipMemcpyAsync(all.data(), eng.d_pcm, (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
+                             hipStreamSynchronize(eng.stream) != hipSuccess)
                         rc = STS_EDEVICE;
                 }
                 if (rc != STS_OK && B > 1) {
@@ -112,6 +113,7 @@ int sts_pool_create(const float* blob, int64_t blob_bytes, int device, int n_eng
     p->max_batch = max_batch;
     for (int k = 0; k < n_engines; k++) {
         p->engines.emplace_back(new Engine());
+        p->engines.back()->host_pcm = true;
         const int rc = p->engines.back()->init(blob, blob_bytes, device);
         if (rc != STS_OK) { pool_err(rc, p->engines.back()->error()); delete p; return rc; }
     }

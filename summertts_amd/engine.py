@@ -71,6 +71,7 @@ def load_library() -> C.CDLL:
     lib.sts_set_record_taps.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_conv_mode.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.sts_set_host_pcm.argtypes = [C.c_void_p, C.c_int]
     lib.sts_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
     lib.sts_get_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64)]
@@ -88,7 +89,7 @@ EXPORTED_SYMBOLS = [
     "sts_create", "sts_destroy", "sts_speaker_num", "sts_get_info", "sts_infer_ids", "sts_infer_ids_batch",
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_profiling",
-    "sts_get_profile", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
+    "sts_get_profile", "sts_set_host_pcm", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
     "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
     "sts_multi_create", "sts_multi_destroy", "sts_multi_device_count", "sts_multi_speaker_num", "sts_multi_infer_ids_batch",
@@ -116,6 +117,11 @@ class Synthesizer:
         _check(self.lib, self.lib.sts_create(blob.ctypes.data, blob.nbytes, device, C.byref(self.h)))
         self.info = ModelInfo()
         _check(self.lib, self.lib.sts_get_info(self.h, C.byref(self.info)))
+        self.set_host_pcm(True)     # run_batch + pcm_host is the common pairing; a device-side gather switches it off
+
+    def set_host_pcm(self, on: bool):
+        """PCM download as part of the run (one stream sync per call); off = the PCM only stays on the device."""
+        _check(self.lib, self.lib.sts_set_host_pcm(self.h, 1 if on else 0))
 
     # -- reference surface -------------------------------------------------------------------
     def get_speaker_num(self) -> int:

@@ -1,82 +1,178 @@
 #!/usr/bin/env python3
-"""Turns rocprofv3 output under gpurun_out/ into the committed summaries under profiles/.
+"""Turns rocprofv3 output (under gpurun_out/) into the committed summaries under profiles/.
 
-  python tools/summarize_profile.py <round-tag> <kernel-trace-dir> [<pmc-fetch-dir> <pmc-write-dir> <steps-in-pmc-run> [<pmc-sq-dir>]]
+  python tools/summarize_profile.py <tag> --workload "<key>" --kt <kernel-trace-dir>
+         [--fetch <pmc FETCH_SIZE dir>] [--write <pmc WRITE_SIZE dir>] [--sq <pmc SQ dir>] [--flow-launches N]
 
-Writes profiles/<tag>_kernel_stats.csv (the --stats table), and, when PMC passes are given,
-profiles/<tag>_pmc.json + profiles/latest_pmc.json with the per-launch HBM traffic of the dominant
-kernel family (conv_mfma_kernel).  FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md (HBM
-section) FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x, so the read side is doubled;
-WRITE_SIZE is uncalibrated and used as reported."""
-import collections
+<key> is bench.py's workload key ("hifigan_sdp|batch=1|phonemes=128|ragged=0").  Writes
+  profiles/<tag>_kernel_stats.csv   the rocprofv3 --stats table of the kernel-trace run
+  profiles/<tag>_timeline.txt       one step of that trace in dispatch order (tools/trace_timeline.py)
+  profiles/<tag>_summary.json       decoder-trunk family (the matrix-core launches bench.py times) and reverse-flow launches:
+                                    launches per step, average duration, HBM bytes per launch from the PMC passes, MFMA-busy
+  profiles/latest_pmc.json          {"by_workload": {<key>: summary}} -- bench.py attaches a summary to its `roofline` object only
+                                    when the workload key AND the kernel build id (sha256 of summertts_amd/csrc) match.
+
+Kernel classes are found by DISPATCH ORDER inside a step (a step starts at embed_kernel): the `--flow-launches` convs after
+expand_frames_kernel are the reverse flow, the next launch is conv_pre, and everything up to the step's last sum_scale_kernel
+(sum_scale itself excluded) is the decoder trunk -- the upsamplers and the grouped / fused ResBlock layers, whichever kernel
+variant the dispatcher picked for them.
+
+FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half the bytes of wide
+coalesced reads, so the read side is doubled; WRITE_SIZE is uncalibrated and used as reported.  The two counters need separate
+passes (TCC slots), and --pmc runs serialise dispatches."""
+import argparse
 import csv
 import glob
+import hashlib
 import json
 import os
+import re
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def newest(pattern):
-    files = glob.glob(pattern) + glob.glob(pattern.replace(os.sep + "*" + os.sep, os.sep))   # with or without the host sub-directory
+def newest(d, suffix):
+    files = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not files:
+        raise SystemExit(f"no *{suffix} under {d}")
     return max(files, key=os.path.getmtime)
 
 
-def counter_sum(d, family):
-    f = newest(os.path.join(d, "*", "*counter_collection.csv"))
-    n, tot = 0, 0.0
+def kernel_build_id():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "summertts_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def short(name):
+    return re.sub(r"\(.*", "", name).replace("void ", "").replace("sts::", "")
+
+
+def classify(names, flow_launches):
+    """names: kernel names of ONE run in dispatch order -> list of labels ('flow', 'trunk', other)."""
+    lab = ["other"] * len(names)
+    starts = [i for i, n in enumerate(names) if "embed_kernel" in n] + [len(names)]
+    for s, e in zip(starts[:-1], starts[1:]):
+        idx = [i for i in range(s, e) if "expand_frames_kernel" in names[i]]
+        if not idx:
+            continue
+        i = idx[0] + 1
+        nconv = 0
+        while i < e and nconv < flow_launches:
+            if "conv_" in names[i]:
+                lab[i] = "flow"
+                nconv += 1
+            i += 1
+        pre = i                                              # conv_pre
+        sums = [k for k in range(pre, e) if "sum_scale_kernel" in names[k]]
+        if not sums:
+            continue
+        for k in range(pre + 1, sums[-1]):
+            if "sum_scale_kernel" not in names[k] and "rocclr" not in names[k]:
+                lab[k] = "trunk"
+    return lab
+
+
+def pmc_rows(d):
+    """-> dispatches in order: [{name, t_ns, counters{}}]"""
+    f = newest(d, "counter_collection.csv")
+    disp = {}
     for r in csv.DictReader(open(f)):
-        if any(f in r["Kernel_Name"] for f in family):
-            n += 1
-            tot += float(r["Counter_Value"])
-    return n, tot
+        k = int(r["Dispatch_Id"])
+        x = disp.setdefault(k, {"name": short(r["Kernel_Name"]), "t_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "c": {}})
+        x["c"][r["Counter_Name"]] = x["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return [disp[k] for k in sorted(disp)]
 
 
 def main():
-    tag, kt = sys.argv[1], sys.argv[2]
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--workload", required=True)
+    ap.add_argument("--kt", required=True)
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--sq")
+    ap.add_argument("--flow-launches", type=int, default=40, help="convs of the reverse flow per step: n_flows * (2 + 2 * wn_layers) [+ n_flows cond convs]")
+    a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    st = newest(os.path.join(kt, "*", "*kernel_stats.csv"))
-    shutil.copy(st, os.path.join(out, f"{tag}_kernel_stats.csv"))
-    # the LDS-staged matrix-core conv: single (upsamplers), grouped (ResBlock chains) and fused-layer (narrow stages) forms
-    fam = ("conv_mfma_kernel", "conv_mfma_group_kernel", "resblock_layer_kernel", "resblock_wino_kernel")
-    rows = [r for r in csv.DictReader(open(st)) if any(f in r["Name"] for f in fam)]
-    calls = sum(int(r["Calls"]) for r in rows)
-    tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
-    summary = {"tag": tag, "kernel_family": " + ".join(fam), "calls": calls, "avg_launch_us_rocprof": tot_ns / max(1, calls) / 1e3}
-    if len(sys.argv) >= 6:
-        nf, fetch_kb = counter_sum(sys.argv[3], fam)
-        nw, write_kb = counter_sum(sys.argv[4], fam)
-        summary.update({
-            "fetch_size_kb_per_launch_raw": fetch_kb / max(1, nf),
-            "write_size_kb_per_launch_raw": write_kb / max(1, nw),
-            "hbm_bytes_per_launch_corrected": (2.0 * fetch_kb / max(1, nf) + write_kb / max(1, nw)) * 1024.0,
-            "correction": "read side x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B); WRITE_SIZE as reported",
-            "launches_in_pmc_run": nf,
-        })
-        json.dump(summary, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)
-    if len(sys.argv) >= 7:      # SQ pass: MFMA-busy of the family (kernels are serialised under --pmc)
-        f = newest(os.path.join(sys.argv[6], "*", "*counter_collection.csv"))
-        disp = {}
-        for r in csv.DictReader(open(f)):
-            if not any(f in r["Kernel_Name"] for f in fam):
-                continue
-            d = disp.setdefault(r["Dispatch_Id"], {"t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
-            d[r["Counter_Name"]] = float(r["Counter_Value"])
-        busy = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for d in disp.values())
-        gui = sum(d.get("GRBM_GUI_ACTIVE", 0.0) for d in disp.values()) / 8.0     # one copy per XCD
-        tns = sum(d["t"] for d in disp.values())
-        summary.update({
-            "mfma_busy_pct_serialised": 100.0 * busy / (1024.0 * gui) if gui else None,   # 256 CUs x 4 SIMDs
-            "shader_clock_ghz": gui / tns if tns else None,
-            "avg_launch_us_serialised": tns / max(1, len(disp)) / 1e3,
-            "hbm_gbps_serialised": summary.get("hbm_bytes_per_launch_corrected", 0.0) / (tns / max(1, len(disp))) if tns else None,
-            "note_serialised": "rocprofv3 --pmc serialises dispatches: dispatches run strictly one after another here",
-        })
-        json.dump(summary, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)
-    json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
+    try:
+        shutil.copy(newest(a.kt, "kernel_stats.csv"), os.path.join(out, f"{a.tag}_kernel_stats.csv"))
+    except SystemExit:
+        pass
+    tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_timeline.py"), a.kt], capture_output=True, text=True).stdout
+    open(os.path.join(out, f"{a.tag}_timeline.txt"), "w").write(tl)
+
+    rows = sorted(csv.DictReader(open(newest(a.kt, "kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
+    names = [short(r["Kernel_Name"]) for r in rows]
+    lab = classify(names, a.flow_launches)
+    nsteps = max(1, sum(1 for n in names if "embed_kernel" in n))
+    summary = {"tag": a.tag, "workload": a.workload, "kernel_build_id": kernel_build_id(), "steps_in_trace": nsteps}
+    for cls in ("trunk", "flow"):
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r, l in zip(rows, lab) if l == cls]
+        kinds = sorted({n for n, l in zip(names, lab) if l == cls})
+        summary[cls] = {"launches_per_step": len(d) / nsteps, "avg_launch_us_rocprof": sum(d) / max(1, len(d)),
+                        "us_per_step_rocprof": sum(d) / nsteps, "kernels": kinds}
+
+    def per_class(d, counter):
+        pr = pmc_rows(d)
+        pl = classify([x["name"] for x in pr], a.flow_launches)
+        res = {}
+        for cls in ("trunk", "flow"):
+            sel = [x for x, l in zip(pr, pl) if l == cls]
+            res[cls] = (len(sel), sum(x["c"].get(counter, 0.0) for x in sel), sum(x["t_ns"] for x in sel), sel)
+        return res
+
+    if a.fetch and a.write:
+        fe, wr = per_class(a.fetch, "FETCH_SIZE"), per_class(a.write, "WRITE_SIZE")
+        for cls in ("trunk", "flow"):
+            nf, fkb, _, _ = fe[cls]
+            nw, wkb, _, _ = wr[cls]
+            summary[cls].update({
+                "fetch_size_kb_per_launch_raw": fkb / max(1, nf), "write_size_kb_per_launch_raw": wkb / max(1, nw),
+                "hbm_bytes_per_launch_corrected": (2.0 * fkb / max(1, nf) + wkb / max(1, nw)) * 1024.0,
+                "launches_in_pmc_run": nf})
+        summary["correction"] = "read side x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B); WRITE_SIZE as reported"
+    if a.sq:
+        sq = per_class(a.sq, "SQ_VALU_MFMA_BUSY_CYCLES")
+        for cls in ("trunk", "flow"):
+            n, busy, tns, sel = sq[cls]
+            gui = sum(x["c"].get("GRBM_GUI_ACTIVE", 0.0) for x in sel) / 8.0          # one copy per XCD
+            summary[cls].update({
+                "mfma_busy_pct_serialised": 100.0 * busy / (1024.0 * gui) if gui else None,     # 256 CUs x 4 SIMDs
+                "shader_clock_ghz": gui / tns if tns else None,
+                "avg_launch_us_serialised": tns / max(1, n) / 1e3})
+            if "hbm_bytes_per_launch_corrected" in summary[cls] and tns:
+                summary[cls]["hbm_gbps_serialised"] = summary[cls]["hbm_bytes_per_launch_corrected"] / (tns / max(1, n))
+        summary["note_serialised"] = "rocprofv3 --pmc serialises dispatches: every launch runs alone here"
+    json.dump(summary, open(os.path.join(out, f"{a.tag}_summary.json"), "w"), indent=1)
+
+    # what bench.py reads
+    latest_path = os.path.join(out, "latest_pmc.json")
+    try:
+        latest = json.load(open(latest_path))
+        if "by_workload" not in latest:
+            latest = {"by_workload": {}}
+    except Exception:
+        latest = {"by_workload": {}}
+    if "hbm_bytes_per_launch_corrected" in summary["trunk"]:
+        t = summary["trunk"]
+        entry = {"tag": a.tag, "kernel_build_id": summary["kernel_build_id"], "correction": summary["correction"],
+                 "hbm_bytes_per_launch_corrected": t["hbm_bytes_per_launch_corrected"], "avg_launch_us_rocprof": t["avg_launch_us_rocprof"],
+                 "flow": {k: summary["flow"].get(k) for k in ("launches_per_step", "us_per_step_rocprof", "hbm_bytes_per_launch_corrected",
+                                                              "hbm_gbps_serialised", "mfma_busy_pct_serialised")}}
+        for k in ("mfma_busy_pct_serialised", "hbm_gbps_serialised"):
+            if k in t:
+                entry[k] = t[k]
+        latest["by_workload"][a.workload] = entry
+        json.dump(latest, open(latest_path, "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
 
