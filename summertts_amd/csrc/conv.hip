@@ -104,7 +104,10 @@ __device__ __forceinline__ void epi_scalar(const ConvArgs& a, int row, size_t op
 constexpr int CK = 16;            // input channels staged per chunk
 constexpr int MAX_HALO = 64;
 
-template <int MW, int NW, int WM, int WN>
+#ifndef STS_RA_GROUP
+#define STS_RA_GROUP 3   // A-fragment ring depth of the grouped (ResBlock) launches; experiment knob of tools/exp_build.sh
+#endif
+template <int MW, int NW, int WM, int WN, int RA = 3>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NTHR = WM * WN * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -224,7 +227,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
     // INPUT prefetch: vmcnt retires in order, so a wait for an A fragment issued after the next chunk's
     // input loads also waits for those (HBM latency); with distance 2 the first such wait comes three
     // steps after the input loads were issued instead of one.
-    float fa[3][CK / 2][MW], fb[2][CK / 2][NW];
+    // (RA = ring depth of the A fragments, prefetch distance RA - 1 steps; the loop is unrolled by UNR = lcm(RA, 2))
+    constexpr int UNR = (RA % 2 == 0) ? RA : 2 * RA;
+    float fa[RA][CK / 2][MW], fb[2][CK / 2][NW];
     int aj = 0, ac = 0;   // tap / chunk of the next A fragment to request
     auto request_a = [&](float (&dst)[CK / 2][MW]) {
         if (!(STS_EXP & 2) || (ac == 0 && aj < 2)) load_a(ac, aj, dst);
@@ -258,16 +263,15 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
         sj = nj; sc = nc;
     };
     load_x(0);
-    request_a(fa[0]);
-    if (nsteps > 1) request_a(fa[1]);
+    static_for<0, RA - 1>([&](auto rc) { constexpr int r = decltype(rc)::value; if (r == 0 || nsteps > r) request_a(fa[r]); });
     store_tile(0);
     __syncthreads();
     load_b(0, 0, fb[0]);
     if (nchunk > 1) load_x(1);
-    for (int s = 0; s < nsteps; s += 6)
-        static_for<0, 6>([&](auto uc) {
+    for (int s = 0; s < nsteps; s += UNR)
+        static_for<0, UNR>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            if (s + u < nsteps) do_step(fa[u % 3], fa[(u + 2) % 3], fb[u % 2], fb[(u + 1) % 2], s + u);
+            if (s + u < nsteps) do_step(fa[u % RA], fa[(u + RA - 1) % RA], fb[u % 2], fb[(u + 1) % 2], s + u);
         });
 
     // ---- epilogue on the accumulator registers -------------------------------------------------
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup 
     // G sits at offset 0 of the kernarg segment; indexing it through the segment pointer keeps the member
     // selection a scalar load (indexing the by-value parameter would spill the whole struct to scratch)
     const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_mfma_body<MW, NW, WM, WN>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
+    conv_mfma_body<MW, NW, WM, WN, STS_RA_GROUP>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -27,6 +27,8 @@ Engine::~Engine() {
     if (arenaF_.base) (void)hipFree(arenaF_.base);
     if (pinned_) (void)hipHostFree(pinned_);
     if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
+    if (hmap_) (void)hipHostFree(hmap_);
+    if (arrive_) (void)hipFree(arrive_);
     if (have_events_) {
         for (auto& e : ev_) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_fork_);
@@ -447,16 +449,46 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         conv(M.fix_proj, bt.dt2, lvT, bt.dr[0], lvT, ConvOpt());
         r_final = bt.dr[0];
     }
+    // ---------------- the one data-dependent sync: frame counts (+ durations for the API).  The durations kernel writes them
+    // straight into host-mapped pinned memory and raises a sequence flag; the host polls that word -- no device-to-host copy
+    // kernel and no stream-synchronise wake-up between the duration predictor and the flow (STS_NO_MAPPED_SYNC=1: the copy path)
+    static const bool no_mapped = getenv("STS_NO_MAPPED_SYNC") != nullptr;
+    const size_t hm_ints = (size_t)Ttot + B + 1;
+    if (!no_mapped && hm_ints > hmap_cap_) {
+        (void)hipStreamSynchronize(stream);
+        if (hmap_) (void)hipHostFree(hmap_);
+        hmap_ = nullptr; hmap_dev_ = nullptr; hmap_cap_ = 0;
+        if (hipHostMalloc((void**)&hmap_, (hm_ints * 2 + 64) * 4, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&hmap_dev_, hmap_, 0) == hipSuccess) { hmap_cap_ = hm_ints * 2 + 64; memset(hmap_, 0, hmap_cap_ * 4); }
+        else { if (hmap_) (void)hipHostFree(hmap_); hmap_ = nullptr; hmap_dev_ = nullptr; }
+        if (!arrive_ && hipMalloc((void**)&arrive_, 64) == hipSuccess) (void)hipMemsetAsync(arrive_, 0, 64, stream);
+    }
+    const bool mapped = !no_mapped && hmap_ && arrive_;
+    if (mapped) { seq_ = seq_ == 0x7fffffff ? 1 : seq_ + 1; }
     durations(r_final, M.dur_type == 0 ? 1 : 0, M.ea_m, M.ea_logs, bt.ls, have_forced ? bt.forced : nullptr, bt.dlogw,
-              bt.dur, bt.cum, bt.frames, lvT.seg, B, stream);
+              bt.dur, bt.cum, bt.frames, lvT.seg, B, stream, mapped ? hmap_dev_ : nullptr, Ttot, seq_, arrive_);
     have_forced = false;
     mark(2);
-    // ---------------- the one data-dependent sync: frame counts (+ durations for the API)
     int* p_down = (int*)(pinned_ + up_bytes);
-    HIPCK(hipMemcpyAsync(p_down, bt.dur, ((size_t)Ttot + B) * 4, hipMemcpyDeviceToHost, stream));
     {
         const auto w0 = std::chrono::steady_clock::now();
-        HIPCK(hipStreamSynchronize(stream));
+        if (mapped) {
+            volatile int* flag = hmap_;                 // word 0 = sequence flag, then dur[Ttot], frames[B]
+            bool ok = false;
+            for (long spin = 0; ; spin++) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_) { ok = true; break; }
+                if ((spin & 0x3ff) == 0x3ff) {      // every ~1k polls: did the stream die?  (a kernel fault would spin forever)
+                    const hipError_t q = hipStreamQuery(stream);
+                    if (q == hipSuccess) { ok = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_; break; }
+                    if (q != hipErrorNotReady) return fail(STS_EDEVICE, std::string("stream failed before the frame counts arrived: ") + hipGetErrorString(q));
+                }
+            }
+            if (!ok) return fail(STS_EDEVICE, "frame counts did not arrive");
+            p_down = hmap_ + 1;
+        } else {
+            HIPCK(hipMemcpyAsync(p_down, bt.dur, ((size_t)Ttot + B) * 4, hipMemcpyDeviceToHost, stream));
+            HIPCK(hipStreamSynchronize(stream));
+        }
         sync_wait_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     }
     durations_h.assign(p_down, p_down + Ttot);

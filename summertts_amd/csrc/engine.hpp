@@ -89,6 +89,8 @@ private:
     Arena arenaT_, arenaF_;
     char* pinned_ = nullptr; size_t pinned_cap_ = 0;
     char* pinned_pcm_ = nullptr; size_t pinned_pcm_cap_ = 0;
+    int* hmap_ = nullptr; int* hmap_dev_ = nullptr; size_t hmap_cap_ = 0;   // host-mapped result block of the durations kernel
+    unsigned* arrive_ = nullptr; int seq_ = 0;
     hipEvent_t ev_[8] = {};
     static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently
     hipStream_t aux_[kAux] = {};

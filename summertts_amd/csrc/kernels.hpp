@@ -162,8 +162,12 @@ void spline_step(const float* h, long ld, float filter_sqrt, const float* r0, co
 // logw -> durations.  sdp: logw = (r0 - ea_m) * exp(-ea_logs) (ElementwiseAffine inverse) else logw = r0.
 // dur[pos] = forced ? forced[pos] : (int)ceil(exp(logw) * ls[b]);  cum[pos] = inclusive prefix inside the
 // utterance;  frames[b] = max(sum, 1).
+// host_out (optional): host-MAPPED pinned memory (device pointer), laid out [flag][dur: total][frames: B] (the flag word is never used for data); every workgroup
+// also writes its results there and the last one to finish publishes `seq` in the flag word -- the host learns the frame
+// counts by polling that word instead of a device-to-host copy + stream synchronisation.  arrive: a zeroed device counter.
 void durations(const float* r0, int sdp, float ea_m, float ea_logs, const float* ls, const int* forced,
-               float* logw_out, int* dur, int* cum, int* frames, SegView seg, int B, hipStream_t st);
+               float* logw_out, int* dur, int* cum, int* frames, SegView seg, int B, hipStream_t st,
+               int* host_out = nullptr, long total = 0, int seq = 0, unsigned* arrive = nullptr);
 // z[c][offF[b] + f] = m[c][offT[b] + phoneme(f)]
 void expand_frames(const float* m, long m_ld, const int* cum, SegView segT, SegView segF, int C,
                    float* z, long z_ld, int B, int max_frames, hipStream_t st);

@@ -392,7 +392,8 @@ void spline_step(const float* h, long ld, float filter_sqrt, const float* r0, co
 constexpr int kMaxDur = 100000;   // sanity clamp per phoneme (the reference has none)
 __global__ __launch_bounds__(256) void durations_kernel(const float* r0, int sdp, float ea_m, float ea_logs,
                                                         const float* ls, const int* forced, float* logw_out,
-                                                        int* dur, int* cum, int* frames, SegView seg) {
+                                                        int* dur, int* cum, int* frames, SegView seg,
+                                                        int* host_out, long total, int seq, unsigned* arrive, int B) {
     __shared__ int wsum[4];
     __shared__ int carry_s;
     const int b = blockIdx.x;
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* r0, int sdp
             }
             if (d < 0) d = 0;
             dur[base + t] = d;
+            if (host_out) host_out[1 + base + t] = d;
         }
         // inclusive scan inside the wave, then across the 4 waves
         int v = d;
@@ -432,11 +434,27 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* r0, int sdp
         __syncthreads();
     }
     if (tid == 0) frames[b] = carry_s < 1 ? 1 : carry_s;
+    if (host_out) {
+        // publish to the host: results first (system scope), then one arrival per workgroup; the last arriver writes the flag
+        if (tid == 0) host_out[1 + total + b] = carry_s < 1 ? 1 : carry_s;
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned prev = atomicAdd(arrive, 1u);
+            if (prev == (unsigned)B - 1u) {
+                *arrive = 0u;                                   // ready for the next run (same stream: ordered)
+                __threadfence_system();
+                __hip_atomic_store(host_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // word 0: never holds data
+            }
+        }
+    }
 }
 void durations(const float* r0, int sdp, float ea_m, float ea_logs, const float* ls, const int* forced,
-               float* logw_out, int* dur, int* cum, int* frames, SegView seg, int B, hipStream_t st) {
+               float* logw_out, int* dur, int* cum, int* frames, SegView seg, int B, hipStream_t st,
+               int* host_out, long total, int seq, unsigned* arrive) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, st, r0, sdp, ea_m, ea_logs, ls, forced, logw_out, dur, cum, frames, seg);
+    hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, st, r0, sdp, ea_m, ea_logs, ls, forced, logw_out, dur, cum, frames, seg,
+                       host_out, total, seq, arrive, B);
 }
 
 // length regulator: frame f of utterance b copies phoneme i with cum[i-1] <= f < cum[i]

@@ -470,3 +470,31 @@ def test_wide_dilation_model_takes_the_checked_paths():
     assert_wave_close(syn.tap("wave")[0], o["wave"], "wide dilation")
     assert_pcm_close(syn.pcm_host(), o["pcm"], "wide dilation")
     syn.close()
+
+
+@pytest.mark.parametrize("width", [256, 32])
+def test_fused_column_layers_at_every_instantiated_width(width):
+    """col_layer_kernel is instantiated for 32 / 64 / 192 / 256 channels (64 and 192 run in every other test): a model whose
+    text encoder AND stochastic duration predictor are `width` wide drives the 16-wave (256) and 2-wave (32) variants, with
+    ragged lengths that leave partial 16-step column blocks, against the oracle."""
+    import dataclasses
+    cfg = dataclasses.replace(sb.tiny_cfg("hifigan_sdp"), hidden=width, sdp_filter=width, n_layers=1, ffn=64)
+    blob = sb.make_blob(cfg, 17)
+    port = pyref.PortModel(blob)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    lens = [37, 16, 5, 49]
+    ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate(lens)]
+    syn.run_batch(ids)
+    x_enc, logw, pcm = syn.tap("x_enc"), syn.tap("logw"), syn.pcm_host()
+    dur = syn.durations(sum(lens))
+    toff = np.concatenate([[0], np.cumsum(lens)])
+    soff = 0
+    for i, a in enumerate(ids):
+        o = port.infer_ids(a, 0, 1.0, taps=True)
+        assert (dur[toff[i]:toff[i + 1]] == o["durations"]).all(), i
+        assert np.abs(x_enc[:, toff[i]:toff[i + 1]] - o["x_enc"]).max() <= TAP_MAXABS_TOL
+        assert np.abs(logw[:, toff[i]:toff[i + 1]] - o["logw"]).max() <= 1e-3
+        assert_pcm_close(pcm[soff:soff + o["pcm"].size], o["pcm"], f"width {width}, utterance {i}")
+        soff += o["pcm"].size
+    syn.close()
