@@ -178,17 +178,148 @@ __global__ __launch_bounds__(64 * NSUB) void col_layer_kernel(ColLayerArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// [embedding | LayerNorm of (a + split-K partials)] -> 1x1 conv to NPASS * C rows (q/k/v projection, encoder output proj).
+// The producer of a text-encoder layer's input and the first conv that consumes it in one launch: the input stage forms
+// x (written out: it is the residual of the layer's post-LayerNorm) and stages it in LDS; the conv then runs NPASS passes
+// of C rows each over the same staged block, the next pass's A strip in flight under the current pass's MFMA chain.
+//   /root/reference/src/modules/attention_encoder.cpp:84-93 (x = LN(x1 + FFN(x1)) -> next layer's q/k/v convs),
+//   /root/reference/src/models/TextEncoder.cpp:54-66 (embedding * sqrt(H)) and :68-70 (proj)
+// ------------------------------------------------------------------------------------------------
+template <int NSUB>
+__global__ __launch_bounds__(64 * NSUB) void col_proj_kernel(ColProjArgs a) {
+    constexpr int C = 16 * NSUB, KQ = C / 4, CG = 4 * NSUB;
+    __shared__ float ys[C * 16];
+    __shared__ float red[2][NSUB][16];
+    const int b = blockIdx.y;
+    const int len = cl_seg_len(a.seg, b);
+    const int n0 = blockIdx.x * 16;
+    if (n0 >= len) return;
+    const size_t base = (size_t)cl_seg_start(a.seg, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const int pos = n0 + col;
+    const bool live = pos < len;
+    const int cg = tid >> 4;
+
+    // ---- input-stage operands first, then pass 0's A strip
+    float v[4], g[4], be[4];
+    if (a.ids) {                                 // embedding lookup (TextEncoder.cpp:54-63; emb_(v, e) = ptr[e * vocab + v])
+        int id = live ? a.ids[base + pos] : 0;
+        if (id < 0 || id >= a.vocab) id = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = live ? a.emb[(size_t)(cg + i * CG) * a.vocab + id] * a.emb_scale : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = cg + i * CG;
+            g[i] = a.gamma[c]; be[i] = a.beta[c];
+            float x0 = live ? a.a[(size_t)c * a.a_ld + base + pos] : 0.f;
+            float pb[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) pb[q] = (live && q < a.nb) ? a.bp[(size_t)q * a.b_stride + (size_t)c * a.b_ld + base + pos] : 0.f;
+            float bs = pb[0];                    // the partials in a fixed order, exactly as layer_norm_kernel adds them
+#pragma unroll
+            for (int q = 1; q < 8; q++) bs += pb[q];
+            v[i] = x0 + bs;
+        }
+    }
+    f32x4 afa[KQ / 4], afb[KQ / 4];
+    auto load_strip = [&](int pass, f32x4 (&dst)[KQ / 4]) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.wc) + ((size_t)pass * NSUB + wave) * (KQ / 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KQ / 4; i++) dst[i] = wp[(size_t)i * 64];
+    };
+    load_strip(0, afa);
+
+    // ---- input stage
+    if (!a.ids) {
+        float s = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { s += v[i]; sq += v[i] * v[i]; }
+        s += __shfl_xor(s, 16, 64); sq += __shfl_xor(sq, 16, 64);
+        s += __shfl_xor(s, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        if (quad == 0) { red[0][wave][col] = s; red[1][wave][col] = sq; }
+        __syncthreads();
+        s = 0.f; sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSUB; k++) { s += red[0][k][col]; sq += red[1][k][col]; }
+        const float mean = s / (float)C;
+        const float var = sq * (float)(1. / (float)C) - mean * mean;
+        const float den = (float)sqrt((double)var + 1e-05);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = ((v[i] - mean) / den) * g[i] + be[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = cg + i * CG;
+        ys[c * 16 + col] = live ? v[i] : 0.f;
+        if (live) a.x_out[(size_t)c * a.x_ld + base + pos] = v[i];
+    }
+    __syncthreads();
+
+    // ---- conv: the staged block is read from LDS once and reused by every pass
+    float bq[KQ];
+#pragma unroll
+    for (int i = 0; i < KQ; i++) bq[i] = ys[(4 * i + quad) * 16 + col];
+    const int rloc = wave * 16 + quad * 4;
+    auto run_pass = [&](int pass, const f32x4 (&af)[KQ / 4]) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KQ; i += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i / 4][i % 4], bq[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[(i + 1) / 4][(i + 1) % 4], bq[i + 1], acc1, 0, 0, 0);
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = pass * C + rloc + r;
+                if (row < a.Cout) a.y[(size_t)row * a.y_ld + base + pos] = (acc0[r] + acc1[r]) + (a.bias ? a.bias[row] : 0.f);
+            }
+        }
+    };
+    for (int pass = 0; pass < a.npass; pass += 2) {          // two strips ping-pong: the next pass's weights are in flight
+        if (pass + 1 < a.npass) load_strip(pass + 1, afb);
+        run_pass(pass, afa);
+        if (pass + 1 < a.npass) {
+            if (pass + 2 < a.npass) load_strip(pass + 2, afa);
+            run_pass(pass + 1, afb);
+        }
+    }
+}
+
+bool col_proj_eligible(const ColProjArgs& a) {
+    if (a.C != 32 && a.C != 64 && a.C != 192) return false;           // instantiated input widths
+    if (!a.wc || !a.y || !a.x_out || a.npass < 1 || a.npass > 4 || a.Cout > a.npass * a.C || a.Cout <= (a.npass - 1) * a.C) return false;
+    if (a.ids) { if (!a.emb || a.vocab <= 0) return false; }
+    else if (!a.a || !a.gamma || !a.beta || a.nb < 0 || a.nb > 8 || (a.nb > 0 && !a.bp)) return false;
+    return a.max_len > 0 && a.B > 0;
+}
+
+void col_proj(const ColProjArgs& a, hipStream_t st) {
+    const dim3 grid((a.max_len + 15) / 16, a.B);
+    switch (a.C) {
+        case 32: hipLaunchKernelGGL((col_proj_kernel<2>), grid, dim3(128), 0, st, a); break;
+        case 64: hipLaunchKernelGGL((col_proj_kernel<4>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((col_proj_kernel<12>), grid, dim3(768), 0, st, a); break;
+    }
+}
+
 // A operand layout of col_layer_kernel for a 1x1 conv with C inputs and C outputs: dst[((wave * (C/16) + i4) * 64 + lane) * 4 + e]
 // = W[cout = 16 wave + (lane & 15)][cin = 4 (4 i4 + e) + (lane >> 4)];  w is the blob's [out][k = 1][in] order.
-void col_layer_pack(const float* w, int C, float* dst) {
-    const int nsub = C / 16, kq4 = C / 16;
-    for (int wave = 0; wave < nsub; wave++)
-        for (int i4 = 0; i4 < kq4; i4++)
-            for (int lane = 0; lane < 64; lane++)
-                for (int e = 0; e < 4; e++) {
-                    const int co = 16 * wave + (lane & 15), ci = 4 * (4 * i4 + e) + (lane >> 4);
-                    dst[(((size_t)wave * kq4 + i4) * 64 + lane) * 4 + e] = w[(size_t)co * C + ci];
-                }
+void col_layer_pack(const float* w, int C, float* dst) { col_proj_pack(w, C, C, dst); }
+// Same order for a 1x1 conv with C inputs and Cout outputs, one C x C block per pass of C output rows (rows >= Cout: zeros):
+// dst[(((pass * (C/16) + wave) * (C/16) + i4) * 64 + lane) * 4 + e] = W[cout = pass C + 16 wave + (lane & 15)][cin = 4 (4 i4 + e) + (lane >> 4)]
+void col_proj_pack(const float* w, int C, int Cout, float* dst) {
+    const int nsub = C / 16, kq4 = C / 16, npass = (Cout + C - 1) / C;
+    for (int pass = 0; pass < npass; pass++)
+        for (int wave = 0; wave < nsub; wave++)
+            for (int i4 = 0; i4 < kq4; i4++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 4; e++) {
+                        const int co = pass * C + 16 * wave + (lane & 15), ci = 4 * (4 * i4 + e) + (lane >> 4);
+                        dst[((((size_t)pass * nsub + wave) * kq4 + i4) * 64 + lane) * 4 + e] = co < Cout ? w[(size_t)co * C + ci] : 0.f;
+                    }
 }
 bool col_layer_width_ok(int C) { return C == 32 || C == 64 || C == 192 || C == 256; }   // instantiated widths (16 * NSUB)
 

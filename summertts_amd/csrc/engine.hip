@@ -363,10 +363,40 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     mark(0);
     // ---------------- TextEncoder (/root/reference/src/models/TextEncoder.cpp:50-74, attention_encoder.cpp:78-94)
     stage_begin(0);
-    embed(bt.ids, M.emb, M.vocab, M.emb_size, sqrtf((float)M.hidden), bt.x, Ttot, (int)Ttot, stream);
+    // The producer of a layer's input x -- the embedding for layer 0, the previous layer's second LayerNorm (which also adds
+    // the FFN's split-K partials) afterwards -- runs inside the launch of the first conv that consumes x (col_proj_kernel)
+    // where the width is instantiated and the grid is small; otherwise as its own launch.
+    static const bool no_colp = getenv("STS_NO_COL_LAYER") != nullptr || getenv("STS_NO_COL_PROJ") != nullptr;   // experiment knobs
+    // Measured (profiles/r02 notes in DESIGN.md 5b): with a handful of column blocks (one 128-phoneme utterance = 8) a
+    // three-pass q/k/v projection makes each of the few workgroups pull 3 x 147 KB of weights through one CU and loses to
+    // the separate LayerNorm + chip-wide conv (23 vs 18 us); from a few dozen blocks on it wins (batch 8: -12 us per layer).
+    // A single-pass conv (the encoder's output projection) wins at every size.
+    const long colp_blocks = (long)((Ttot + 15) / 16);
+    const bool colp_grid = (long)((maxT + 15) / 16) * B <= 512;
+    auto produce_x_and_conv = [&](int l, const DConv& c, float* y) {
+        // l = index of the layer whose input is produced (l == n_layers: the encoder's output projection)
+        ColProjArgs pj;
+        memset(&pj, 0, sizeof(pj));
+        pj.x_out = bt.x; pj.x_ld = Ttot; pj.wc = c.wc; pj.bias = c.bias_rows; pj.Cout = c.Cout; pj.npass = (c.Cout + H - 1) / H;
+        pj.y = y; pj.y_ld = Ttot; pj.C = H; pj.seg = lvT.seg; pj.B = B; pj.max_len = maxT;
+        if (l == 0) { pj.ids = bt.ids; pj.emb = M.emb; pj.vocab = M.vocab; pj.emb_scale = sqrtf((float)M.hidden); }
+        else { pj.a = bt.x1; pj.a_ld = Ttot; pj.bp = bt.y; pj.b_ld = Ttot; pj.nb = ffn2_slices; pj.b_stride = (long)H * Ttot;
+               pj.gamma = M.ln2[l - 1].g; pj.beta = M.ln2[l - 1].b; }
+        const bool ok = !no_colp && conv_mode != 1 && colp_grid && (pj.npass == 1 || colp_blocks >= 24) && c.k == 1 && c.Cin == H && M.emb_size == H && c.wc &&
+                        (l == 0 || M.ln2[l - 1].C == H) && col_proj_eligible(pj);
+        if (ok) {
+            flops_[0] += 2.0 * c.macs_per_out * (double)Ttot;
+            bytes_[0] += 4.0 * ((double)H * Ttot * (l == 0 ? 1.0 : 2.0 + ffn2_slices) + (double)c.Cout * Ttot + (double)H * c.Cout);
+            col_proj(pj, stream);
+            return;
+        }
+        if (l == 0) embed(bt.ids, M.emb, M.vocab, M.emb_size, sqrtf((float)M.hidden), bt.x, Ttot, (int)Ttot, stream);
+        else ln(M.ln2[l - 1], bt.x1, bt.y, nullptr, bt.x, lvT, 0, 0, ffn2_slices, (long)H * Ttot);
+        conv(c, bt.x, lvT, y, lvT, ConvOpt());
+    };
     for (int l = 0; l < M.n_layers; l++) {
         const DMha& a = M.mha[l];
-        conv(a.qkv, bt.x, lvT, bt.qkv, lvT, ConvOpt());
+        produce_x_and_conv(l, a.qkv, bt.qkv);
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.q = bt.qkv; at.k = bt.qkv + (size_t)H * Ttot; at.v = bt.qkv + (size_t)2 * H * Ttot; at.o = bt.att; at.ld = Ttot;
@@ -398,9 +428,9 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         // few output tiles, long K: split K over workgroups into partial outputs that the LayerNorm below adds up
         o2.kslices = ffn2_slices; o2.kslice_stride = (long)H * Ttot;
         conv(f.c2, bt.ffh, lvT, bt.y, lvT, o2);
-        ln(M.ln2[l], bt.x1, bt.y, nullptr, bt.x, lvT, 0, 0, ffn2_slices, (long)H * Ttot);
+        // (the layer's second LayerNorm runs with the next consumer of x: the next layer's q/k/v conv or the output proj)
     }
-    conv(M.proj, bt.x, lvT, bt.m, lvT, ConvOpt());
+    produce_x_and_conv(M.n_layers, M.proj, bt.m);
     tap("x_enc", bt.x, H, Ttot, Ttot);
     tap("m", bt.m, C, Ttot, Ttot);
     mark(1);

@@ -109,6 +109,21 @@ bool col_layer_width_ok(int C);
 void col_layer_pack(const float* w, int C, float* dst);
 void col_layer(const ColLayerArgs& a, hipStream_t st);
 
+// [embedding | LayerNorm(a + partials)] -> x_out, then y = conv1x1(x_out) with npass * C output rows (col_layer.hip)
+struct ColProjArgs {
+    const int* ids; const float* emb; int vocab; float emb_scale;        // embedding form (ids != null)
+    const float* a; long a_ld; const float* bp; long b_ld; int nb; long b_stride;   // LayerNorm form: v = a + bp_0 + ... + bp_{nb-1}
+    const float* gamma; const float* beta;
+    float* x_out; long x_ld;                    // the staged input, also written out (residual of the layer's post-LayerNorm)
+    const float* wc; const float* bias; int Cout, npass;    // weights in col_proj_pack order, bias in plain row order
+    float* y; long y_ld;
+    int C;
+    SegView seg; int B, max_len;
+};
+bool col_proj_eligible(const ColProjArgs& a);
+void col_proj(const ColProjArgs& a, hipStream_t st);
+void col_proj_pack(const float* w, int C, int Cout, float* dst);
+
 struct AttnArgs {
     const float* q; const float* k; const float* v; float* o; long ld;
     const float* relk; const float* relv;   // [kc][px] (reference column-major [px, kc])

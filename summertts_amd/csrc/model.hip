@@ -135,11 +135,15 @@ bool pack_wino(Store& st, const HConv& h, DConv& d) {
 }
 
 // extra copy of a square 1x1 conv in the fused column-block kernel's operand order (col_layer.hip)
-bool pack_col(Store& st, const HConv& h, DConv& d) {
-    if (h.k != 1 || h.in_ch != h.out_ch || d.depthwise || !col_layer_width_ok(h.in_ch)) return true;
-    float* p = st.alloc((size_t)h.in_ch * h.in_ch, &d.wc);
+bool pack_col(Store& st, const HConv& h, DConv& d, int out_rows = -1) {
+    const int rows = out_rows > 0 ? out_rows : h.out_ch;
+    if (h.k != 1 || d.depthwise || !col_layer_width_ok(h.in_ch) || rows < h.in_ch) return true;
+    const int npass = (rows + h.in_ch - 1) / h.in_ch;
+    if (npass > 4) return true;
+    float* p = st.alloc((size_t)npass * h.in_ch * h.in_ch, &d.wc);
     if (!p) { d.wc = nullptr; return false; }
-    col_layer_pack(h.w, h.in_ch, p);
+    col_proj_pack(h.w, h.in_ch, rows, p);
+    d.bias_rows = d.bias;       // plain convs are packed in source row order
     return true;
 }
 
@@ -293,7 +297,8 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         }
         HConv cat; cat.out_ch = 3 * a.ch; cat.in_ch = a.ch; cat.k = 1; cat.pad = 0; cat.dil = 1; cat.has_bias = anyb ? 1 : 0;
         cat.w = wcat.data(); cat.b = bcat.data();
-        if (!pack_conv(st, cat, PackOpts(), a.qkv) || !pack_conv(st, o, PackOpts(), a.o) || !pack_col(st, o, a.o)) FAIL("weight store overflow");
+        if (!pack_conv(st, cat, PackOpts(), a.qkv) || !pack_conv(st, o, PackOpts(), a.o) || !pack_col(st, o, a.o) || !pack_col(st, cat, a.qkv))
+            FAIL("weight store overflow");
     }
     for (int i = 0; i < m.n_layers; i++) { HLn h = parse_ln(r); if (!r.ok || !pack_ln(st, h, m.ln1[i])) FAIL("ln1"); }
     for (int i = 0; i < m.n_layers; i++) {   // /root/reference/src/modules/ffn.cpp:27-30
@@ -309,7 +314,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         m.inter = p.out_ch / 2;
         // `logs` (second half) is dead at noiseScale == 0 (/root/reference/src/models/SynthesizerTrn.cpp:357,383): keep m only
         PackOpts o; o.out_rows = m.inter;
-        if (!pack_conv(st, p, o, m.proj)) FAIL("proj pack");
+        if (!pack_conv(st, p, o, m.proj) || !pack_col(st, p, m.proj, m.inter)) FAIL("proj pack");
     }
 
     // ---- decoder: Generator_hifigan.cpp:44-101, Generator_MS.cpp:51-127, Generator_Istft.cpp:49-113, Generator_MBB.cpp:51-106

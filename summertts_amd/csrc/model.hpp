@@ -30,7 +30,8 @@ struct DConv {
     int gate_perm = 0, H = 0;
     const float* w = nullptr;
     const float* bias = nullptr;
-    const float* wc = nullptr;      // col_layer_kernel's A-strip copy of a square 1x1 conv (DDSConv pointwise convs, attention o-proj)
+    const float* wc = nullptr;      // col_layer / col_proj A-strip copy of a 1x1 conv (DDSConv pointwise convs, attention o-proj, q/k/v, encoder proj)
+    const float* bias_rows = nullptr;   // bias in source row order next to wc (== bias where the conv's rows are not permuted)
     const float* wu = nullptr;      // Winograd-domain copy [seg][4][Cin_pad][Cout_pad] (narrow decoder ResBlock convs)
     double macs_per_out = 0;   // true-tap MACs per output position (all output channels)
 };
