@@ -4,6 +4,7 @@
 // wave64 shuffles; every kernel reads/writes time-contiguous rows so global accesses coalesce.
 #include "kernels.hpp"
 #include "devmath.hpp"
+#include <stdlib.h>
 
 namespace sts {
 
@@ -227,8 +228,198 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         }
     }
 }
+// ---------------------------------------------------------------------------------------------
+// The same attention on the matrix cores, 16 queries per workgroup (round 2).  The kernel above re-reads an utterance's
+// K and V once per query (2 x kc x T floats per workgroup): fine for one short utterance, but 46 % of the text encoder's
+// time at batch 8 (profiles/r02_b8_kernel_stats.csv: 98 us per launch).  Here a workgroup (4 waves) owns a block of 16
+// queries of one head:
+//   S^T tiles [16 keys x 16 queries] = K^T q on v_mfma_f32_16x16x4_f32, one 16-key tile per wave at a time, K fragments
+//     straight from global memory (lanes run along the keys: 64-byte segments), q fragments from LDS;
+//   + banded relative-key logits, exp (no max shift, nn_softmax.cpp:5-28), row sums through shuffles + LDS, P normalised
+//     in LDS in [key][query] order;
+//   O = P V: keys are the reduction axis, so V is staged through LDS in 64-key chunks ([key][channel], padded against bank
+//     conflicts), every wave takes a quarter of each chunk's key steps for all kc / 16 channel tiles, the four partial
+//     accumulators meet through LDS; the banded relative-value term is added per output element.
+// K and V are read once per 16 queries instead of once per query.
+typedef float attn_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int ATT_VLD_PAD = 16;     // vbuf row = kc + 16 floats: quads of a half-wave land in distinct banks
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a, int Tpad) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16;
+    const int T = seg_len(a.seg, b);
+    if (i0 >= T) return;
+    const size_t base = (size_t)seg_start(a.seg, b);
+    const int kc = a.kc, px = a.px, win = a.win;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const int VLD = kc + ATT_VLD_PAD;
+    float* qs = sm;                          // [kc][16]   q / sqrt(kc), zero for queries past the end
+    float* qrel = qs + kc * 16;              // [16][32]   q . relK[:, r]
+    float* rsum = qrel + 16 * 32;            // [4][16]
+    float* P = rsum + 64;                    // [Tpad][16] exp(S) then softmax, [key][query]
+    float* vbuf = P + (size_t)Tpad * 16;     // [64][VLD]  one V chunk; later the partial outputs [4][kc/16][64][4]
+    const float sq = sqrtf((float)kc);
+    {   // all of a thread's q loads are issued together (kc <= 128: at most 8 per thread)
+        float qv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = tid + u * 256, c = e >> 4, i = e & 15;
+            qv[u] = (e < kc * 16 && i0 + i < T) ? a.q[(size_t)(h * kc + c) * a.ld + base + i0 + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int e = tid + u * 256; if (e < kc * 16) qs[e] = qv[u] / sq; }
+    }
+    __syncthreads();
+    if (win > 0)
+        for (int e = tid; e < 16 * px; e += 256) {
+            const int i = e & 15, r = e >> 4;
+            float s = 0.f;
+            for (int c0 = 0; c0 < kc; c0 += 16) {        // 16 independent table loads per round
+                float rk[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) rk[u] = a.relk[(size_t)(c0 + u) * px + r];
+#pragma unroll
+                for (int u = 0; u < 16; u++) s += qs[(c0 + u) * 16 + i] * rk[u];
+            }
+            qrel[i * 32 + r] = s;
+        }
+    __syncthreads();
+
+    // ---- scores: wave w takes key tiles w, w + 4, ...
+    float part[4] = {0.f, 0.f, 0.f, 0.f};    // row-sum partials of queries 4 quad + r (over this wave's tiles, this lane's key)
+    const int ntile = (T + 15) / 16;
+    for (int jt = wave; jt < ntile; jt += 4) {
+        const int j = jt * 16 + col;         // this lane's key
+        const bool kv = j < T;
+        attn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* kp = a.k + (size_t)(h * kc) * a.ld + base + (kv ? j : 0);
+        {   // the tile's whole K fragment (kc / 4 <= 32 k-steps of 4 channels) is requested at once
+            float kb[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) { const int c = 4 * u + quad; kb[u] = (kv && c < kc) ? kp[(size_t)c * a.ld] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+                const int c = 4 * u + quad;
+                if (4 * u < kc) {
+                    const float qa = qs[c * 16 + col];     // A[i = col][k = quad] = q of query col, channel c
+                    // D[row = 4 quad + r][col]: rows = A's i index = QUERY, cols = B's j index = KEY
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, kb[u], acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = 4 * quad + r;                // query of this accumulator row; key = j (this lane's column)
+            float sc = acc[r];
+            const int rr = j - (i0 + i) + win;
+            if (win > 0 && rr >= 0 && rr < px) sc += qrel[i * 32 + rr];
+            const float e = (kv && i0 + i < T) ? expf(sc) : 0.f;
+            P[(size_t)j * 16 + i] = e;                 // j < Tpad always
+            part[r] += e;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {                      // sum over the 16 keys held by the lanes of this quad
+        float v = part[r];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (col == 0) rsum[wave * 16 + 4 * quad + r] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < ntile * 256; e += 256) {     // P = exp / sum   (nn_softmax.cpp: divide every element by the row sum)
+        const int i = e & 15;
+        const float sum = (rsum[i] + rsum[16 + i]) + (rsum[32 + i] + rsum[48 + i]);
+        P[e] = P[e] / sum;
+    }
+    __syncthreads();
+
+    // ---- O = P V: 64-key chunks of V through LDS; wave w takes k-steps w, w + 4, ... of every chunk
+    const int nct = kc / 16;                           // channel tiles (<= 8)
+    attn_f32x4 oacc[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) oacc[n] = attn_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        // stage V[kc][64 keys] -> vbuf[key][channel]; a thread reads runs of keys (coalesced) for one channel at a time
+        for (int e0 = tid; e0 < kc * 64; e0 += 256 * 8) {      // 8 loads in flight per thread
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * 256, c = e >> 6, jj = e & 63;
+                vv[u] = (e < kc * 64 && j0 + jj < T) ? a.v[(size_t)(h * kc + c) * a.ld + base + j0 + jj] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * 256, c = e >> 6, jj = e & 63;
+                if (e < kc * 64) vbuf[jj * VLD + c] = vv[u];
+            }
+        }
+        __syncthreads();
+        for (int ks = wave; ks < 16; ks += 4) {
+            const int jj = 4 * ks + quad;              // key inside the chunk
+            if (j0 + 4 * ks >= T) break;
+            const float pa = P[(size_t)(j0 + jj) * 16 + col];          // A[i = col][k = quad] = P[query col][key jj]  (zero past T)
+#pragma unroll
+            for (int n = 0; n < 8; n++)
+                if (n < nct) oacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vbuf[jj * VLD + n * 16 + col], oacc[n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- combine the four waves' partial outputs (vbuf is free now): red[wave][n][lane][r]
+    float* red = vbuf;
+#pragma unroll
+    for (int n = 0; n < 8; n++)
+        if (n < nct) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[((wave * 8 + n) * 64 + lane) * 4 + r] = oacc[n][r];
+        }
+    __syncthreads();
+    // D[row = 4 quad + r -> query][col -> channel n 16 + col]; one output element per (n, lane, r)
+    for (int e = tid; e < nct * 256; e += 256) {
+        const int n = e >> 8, ln = (e >> 2) & 63, r = e & 3;
+        const int i = 4 * (ln >> 4) + r, ch = n * 16 + (ln & 15);
+        if (i0 + i >= T) continue;
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) o += red[((w * 8 + n) * 64 + ln) * 4 + r];
+        float orel = 0.f;
+        if (win > 0) {
+            float rv[32];
+#pragma unroll
+            for (int rr = 0; rr < 32; rr++) rv[rr] = rr < px ? a.relv[(size_t)ch * px + rr] : 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 32; rr++) {
+                const int jj = i0 + i + rr - win;
+                if (rr < px && jj >= 0 && jj < T) orel += P[(size_t)jj * 16 + i] * rv[rr];
+            }
+        }
+        a.o[(size_t)(h * kc + ch) * a.ld + base + i0 + i] = o + orel;
+    }
+}
+
+static size_t attention_mfma_lds(const AttnArgs& a, int Tpad) {
+    const size_t red = (size_t)4 * 8 * 64 * 4, vb = (size_t)64 * (a.kc + ATT_VLD_PAD);
+    return ((size_t)a.kc * 16 + 16 * 32 + 64 + (size_t)Tpad * 16 + (vb > red ? vb : red)) * sizeof(float);
+}
+
 void attention(const AttnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
+    {   // matrix-core form: 16 queries per workgroup, whenever its LDS footprint fits and the model shape is covered
+        static const bool no_mfma = getenv("STS_NO_ATTN_MFMA") != nullptr;   // experiment knob
+        const int Tpad = (a.max_len + 63) / 64 * 64;
+        const size_t lds = attention_mfma_lds(a, Tpad);
+        // Measured: the block kernel is one long dependent chain per workgroup -- with 16 workgroups (one
+        // 128-phoneme utterance) it takes 26 us against 11.5 us for the one-query-per-workgroup kernel; from about a
+        // hundred workgroups on it wins (batch 8: 98 -> 45 us per launch, text encoder 1.21 -> 0.88 ms)
+        const long wgs = (long)((a.max_len + 15) / 16) * a.nheads * a.B;
+        const char* mw = getenv("STS_ATTN_MFMA_MIN_WGS");       // test / experiment knob (read per call): threshold override
+        const long min_wgs = mw ? atol(mw) : 96;
+        if (!no_mfma && wgs >= min_wgs && a.kc % 16 == 0 && a.kc <= 128 && a.px <= 32 && lds <= 150 * 1024) {
+            if (lds > 48 * 1024)
+                hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(attention_mfma_kernel, dim3((a.max_len + 15) / 16, a.nheads, a.B), dim3(256), lds, st, a, Tpad);
+            return;
+        }
+    }
     size_t lds = (size_t)(a.kc + 8 + (a.px > 16 ? a.px : 16) + 5 * (size_t)a.max_len) * sizeof(float);
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

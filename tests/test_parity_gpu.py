@@ -498,3 +498,30 @@ def test_fused_column_layers_at_every_instantiated_width(width):
         assert_pcm_close(pcm[soff:soff + o["pcm"].size], o["pcm"], f"width {width}, utterance {i}")
         soff += o["pcm"].size
     syn.close()
+
+
+@pytest.mark.parametrize("kind", ["hifigan_sdp", "ms_hifigan_fix", "mbb_fix"])
+def test_block_attention_kernel_matches_oracle_at_every_size(kind, monkeypatch):
+    """attention_mfma_kernel (16 queries per workgroup on the matrix cores) normally engages from ~100 workgroups on; here it is
+    forced for tiny models and ragged lengths (partial 16-query blocks, a 1-phoneme utterance, keys past the last 64-key chunk)
+    and the text-encoder output is compared with the oracle utterance by utterance."""
+    monkeypatch.setenv("STS_ATTN_MFMA_MIN_WGS", "1")
+    cfg = sb.tiny_cfg(kind)
+    blob = sb.make_blob(cfg, 23)
+    port = pyref.PortModel(blob)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    lens = [70, 16, 1, 33, 129]
+    ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate(lens)]
+    sid = [i % syn.get_speaker_num() for i in range(len(lens))]
+    syn.run_batch(ids, sid)
+    x_enc, pcm, dur = syn.tap("x_enc"), syn.pcm_host(), syn.durations(sum(lens))
+    toff = np.concatenate([[0], np.cumsum(lens)])
+    soff = 0
+    for i, a in enumerate(ids):
+        o = port.infer_ids(a, sid[i], 1.0, taps=True)
+        assert np.abs(x_enc[:, toff[i]:toff[i + 1]] - o["x_enc"]).max() <= TAP_MAXABS_TOL, (kind, i)
+        assert (dur[toff[i]:toff[i + 1]] == o["durations"]).all()
+        assert_pcm_close(pcm[soff:soff + o["pcm"].size], o["pcm"], f"{kind} utterance {i}")
+        soff += o["pcm"].size
+    syn.close()
