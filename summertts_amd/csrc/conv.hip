@@ -1378,6 +1378,9 @@ void conv_mfma(const ConvArgs& a, hipStream_t st, int tile) {
         // a short, K-heavy transposed conv (HiFi-GAN's first upsampler at one utterance: 669 positions, K = 2 x 512) leaves the
         // LDS-staged grid at ~3 long workgroups per CU; split over waves it runs 84 -> 51 us (profiles/r01_conv_microbench.log)
         else if (a.transposed && blocks < 1024 && (long)a.ntap * (a.Cin_pad / 8) >= 128 && fits32) { splitk = true; nw = 2; }
+        // a 1x1 conv has no taps to share a staged window between: the LDS tile (one barrier per 16-channel chunk) is pure
+        // overhead for K <= 256, at any grid size (flow res/skip conv at batch 8: 43 -> 38 us, MB-iSTFT batch 64 flow -6 %)
+        else if (a.ntap == 1 && !a.transposed && a.Cin_pad <= 256 && fits32) { splitk = true; nw = 1; }
     }
     if (splitk) {
         if (nw == 2) launch_splitk<1, 2>(a, nphase, st); else launch_splitk<1, 1>(a, nphase, st);
@@ -1457,13 +1460,23 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
         const int j = i / a.Cin, ci = i - j * a.Cin;
         ws[i] = a.w[((size_t)j * a.Cin_pad + ci) * a.Cout_pad];
     }
-    for (int ci = 0; ci < a.Cin; ci++) {
-        const float* xrow = a.x + (size_t)ci * a.x_ld + in_base;
-        for (int col = threadIdx.x; col < W; col += 256) {
-            const int pos = n0 + a.tap_off + col;
-            float v = (pos >= 0 && pos < in_len) ? xrow[pos] : 0.f;
-            if (a.in_act) v = v < 0.f ? v * a.in_slope : v;
-            xs[(size_t)ci * W + col] = v;
+    // window staging: 8 rows per round, all of a round's loads issued before any is used (the kernel is pure HBM streaming:
+    // one dependent load per row made it latency-bound at ~0.8 TB/s)
+    for (int col = threadIdx.x; col < W; col += 256) {
+        const int pos = n0 + a.tap_off + col;
+        const bool ok = pos >= 0 && pos < in_len;
+        const float* xcol = a.x + in_base + (ok ? pos : 0);
+        for (int c0 = 0; c0 < a.Cin; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (ok && c0 + u < a.Cin) ? xcol[(size_t)(c0 + u) * a.x_ld] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (c0 + u < a.Cin) {
+                    float t = v[u];
+                    if (a.in_act) t = t < 0.f ? t * a.in_slope : t;
+                    xs[(size_t)(c0 + u) * W + col] = t;
+                }
         }
     }
     __syncthreads();

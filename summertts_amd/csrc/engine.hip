@@ -594,15 +594,16 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         float* dst = bf.z + (size_t)(cp.flipped ? 0 : half) * Ftot;
         const DWn& w = cp.wn;
         if (w.has_cond) conv(w.cond, bt.g, lvB, bt.cond_wn, lvB, ConvOpt());
-        conv(cp.pre, x0, lv1, bf.h, lv1, ConvOpt());
+        static const int flow_1x1_tile = getenv("STS_FLOW_1X1_TILE") ? atoi(getenv("STS_FLOW_1X1_TILE")) : -1;   // experiment knob
+        { ConvOpt op; op.tile = flow_1x1_tile; conv(cp.pre, x0, lv1, bf.h, lv1, op); }
         for (int l = 0; l < w.n; l++) {
             ConvOpt og; og.epi = EPI_GATE;
             if (w.has_cond) og.ubias = bt.cond_wn + (size_t)l * 2 * w.H * B;
             conv(w.in[l], bf.h, lv1, bf.acts, lv1, og);
-            ConvOpt orr; orr.epi = EPI_RESSKIP; orr.epi_flag = l == 0 ? 1 : 0; orr.aux = bf.out;
+            ConvOpt orr; orr.epi = EPI_RESSKIP; orr.epi_flag = l == 0 ? 1 : 0; orr.aux = bf.out; orr.tile = flow_1x1_tile;
             conv(w.rs[l], bf.acts, lv1, bf.h, lv1, orr);
         }
-        ConvOpt os; os.epi = EPI_SUB;
+        ConvOpt os; os.epi = EPI_SUB; os.tile = flow_1x1_tile;
         conv(cp.post, bf.out, lv1, dst, lv1, os);
     }
     if (M.n_flows & 1) flip_channels(bf.z, Ftot, C, Ftot, bf.fliptmp, stream);
