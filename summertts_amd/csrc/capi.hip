@@ -222,6 +222,14 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         wu.resize((size_t)(wn3 + wn2) * 4 * Cin_pad * Cout_pad);
         wino_pack(w, (long)k * Cin, Cin, 1, Cout, k, Cin, Cin_pad, Cout_pad, wu.data());
     }
+    // modes 13 / 20..27: the split-bf16 kernel (conv_bf3.hip), automatic tile / tile (mode - 20)
+    const bool bf3 = (mode == 13 || (mode >= 20 && mode < 28)) && !depthwise;
+    std::vector<unsigned char> wb3;
+    if (bf3) {
+        wb3.resize(bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, nullptr));
+        bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, wb3.data());
+    }
+    void* dwb3 = nullptr;
     float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dwu = nullptr; int* dseg = nullptr;
     int seg[2] = {0, 1};
     bool ok = hipMalloc((void**)&dx, (size_t)Cin * L * 4) == hipSuccess && hipMalloc((void**)&dw, (wn + 1024) * 4) == hipSuccess &&
@@ -229,6 +237,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
               hipMalloc((void**)&dseg, 8) == hipSuccess;
     int rc = STS_OK;
     if (ok && !wu.empty()) ok = hipMalloc((void**)&dwu, (wu.size() + 1024) * 4) == hipSuccess;
+    if (ok && bf3) ok = hipMalloc(&dwb3, wb3.size() + 4096) == hipSuccess;
     if (!ok) rc = set_err(STS_EDEVICE, "hipMalloc failed");
     if (rc == STS_OK) {
         (void)hipMemcpy(dx, x, (size_t)Cin * L * 4, hipMemcpyHostToDevice);
@@ -247,13 +256,16 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         // segment lengths in base units: in = L, out = Lout -> two views over the same {off=0,len=1} table
         a.in_seg = SegView{dseg, dseg + 1, L, 0}; a.out_seg = SegView{dseg, dseg + 1, Lout, 0}; a.B = 1;
         if (dwu) { (void)hipMemcpy(dwu, wu.data(), wu.size() * 4, hipMemcpyHostToDevice); a.wu = dwu; a.wino_n3 = wn3; a.wino_n2 = wn2; }
+        if (dwb3) { (void)hipMemcpy(dwb3, wb3.data(), wb3.size(), hipMemcpyHostToDevice); a.wb3 = dwb3; }
         auto launch = [&]() {
-            if (mode == 12) conv_wino(a, nullptr);
+            if (bf3) conv_bf3(a, nullptr, mode == 13 ? -1 : mode - 20);
+            else if (mode == 12) conv_wino(a, nullptr);
             else if (mode != 1 && conv_mfma_eligible(a)) conv_mfma(a, nullptr, mode >= 2 ? mode - 2 : -1);
             else conv_generic(a, nullptr);
         };
-        if (mode == 12 && !conv_wino_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the Winograd kernel");
-        else if (mode >= 2 && mode != 12 && !conv_mfma_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the matrix-core kernel");
+        if (bf3 && !conv_bf3_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the split-bf16 kernel");
+        else if (mode == 12 && !conv_wino_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the Winograd kernel");
+        else if (!bf3 && mode >= 2 && mode != 12 && !conv_mfma_eligible(a)) rc = set_err(STS_EINVAL, "shape not eligible for the matrix-core kernel");
         else launch();
         if (rc == STS_OK && iters > 0 && ms_out) {   // steady-state timing of the same launch (HIP events, null stream)
             hipEvent_t e0, e1;
@@ -275,7 +287,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
             *y_out = y; *Lout_out = Lout;
         }
     }
-    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dseg); if (dwu) (void)hipFree(dwu);
+    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dseg); if (dwu) (void)hipFree(dwu); if (dwb3) (void)hipFree(dwb3);
     return rc;
 }
 

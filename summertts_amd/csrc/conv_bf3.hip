@@ -1,0 +1,419 @@
+// conv_bf3.hip -- fp32 Conv1d / ConvTranspose1d on the BF16 matrix cores of gfx950 (v_mfma_f32_32x32x16_bf16).
+//
+// Same contract as conv.hip's kernels (they replace /root/reference/src/nn_op/nn_conv1d.cpp:118-199 and
+// nn_conv1d_transposed.cpp:106-150), same ConvArgs, same epilogues -- a different way of doing the fp32 arithmetic.
+// gfx950 has no TF32-like mode and its exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate
+// (MI355X_MICROARCH.md: 157 TF/s vs 2.5 PF/s).  An fp32 number is the EXACT sum of three bf16 numbers
+//     x = hi + mid + lo,   hi = trunc_bf16(x), mid = trunc_bf16(x - hi), lo = x - hi - mid      (8 + 8 + 8 mantissa bits)
+// so a product of two fp32 numbers is the sum of nine bf16 x bf16 products, each of which the matrix core forms exactly
+// and accumulates in fp32.  The three products of relative order 2^-24 and below (mid*lo, lo*mid, lo*lo) are dropped --
+// that is the size of the rounding error an fp32 multiply-add makes anyway -- leaving SIX bf16 MFMAs per fp32 MFMA-equivalent:
+// 6/16 of the matrix-pipe time of the exact-fp32 instruction.  Measured against fp64 the result is as accurate as the
+// fp32 MFMA kernels' (tests/test_parity_gpu.py::test_bf3_conv_*); every parity tolerance is unchanged.
+//
+// Layout follows from the instruction: a lane feeds 8 CONSECUTIVE k values (input channels) of one row / column.
+//   * weights are split and fragment-packed at load time (bf3_pack): [phase][chunk of 16 cin][tap][32-row tile][plane][lane][8],
+//     so an A fragment is one 16-byte load per lane, 1 KB contiguous per wave, (step, row tile, plane) in the scalar offset;
+//   * the input window of a 16-channel chunk is staged ONCE in LDS, already split, channel-minor: plane[pos][16 cin] bf16
+//     (32 B per position and plane; the 16-byte half a lane reads is XOR-swizzled with bit 3 of the position, which
+//     makes every ds_read_b128 lane group hit 16 distinct 16-byte bank slots for ANY tap shift).  The transposition
+//     (global memory is channel-major, time contiguous) happens in the staging registers: lane (pos, half) loads its 8
+//     channels of one position (every load instruction reads two full 128-byte lines), applies the fused input
+//     activation, splits, and writes three 16-byte vectors.  The split costs ~7 VALU ops per staged element and is
+//     amortised over all output rows and taps that read it;
+//   * a wave owns a (32 MW) x (32 NW) output tile: every A fragment is reused over NW column tiles and every B fragment
+//     over MW row tiles, 6 MW NW MFMAs per (chunk, tap) step, accumulators interleaved so no MFMA waits for its predecessor.
+#include "kernels.hpp"
+#include "devmath.hpp"
+#include "conv_common.hpp"
+
+#include <string.h>
+
+namespace sts {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef STS_BF3_RA
+#define STS_BF3_RA 2     // A-fragment ring depth (prefetch distance RA - 1 steps)
+#endif
+
+// exact three-way split of 8 fp32 values (one lane's 8 channels) into bf16 planes; element e of a plane sits in the low
+// (e even) / high (e odd) half of dword e / 2 -- the order v_mfma_*_bf16 reads its 8 k values in
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const unsigned ua = __builtin_bit_cast(unsigned, x[2 * d]), ub = __builtin_bit_cast(unsigned, x[2 * d + 1]);
+        hi[d] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+        const float ra = x[2 * d] - __builtin_bit_cast(float, ua & 0xffff0000u);
+        const float rb = x[2 * d + 1] - __builtin_bit_cast(float, ub & 0xffff0000u);
+        const unsigned va = __builtin_bit_cast(unsigned, ra), vb = __builtin_bit_cast(unsigned, rb);
+        mid[d] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+        const float la = ra - __builtin_bit_cast(float, va & 0xffff0000u);
+        const float lb = rb - __builtin_bit_cast(float, vb & 0xffff0000u);
+        lo[d] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, lb), __builtin_bit_cast(unsigned, la), 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// the six products, smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); planes 0 / 1 / 2 = hi / mid / lo
+constexpr int kProdA[6] = {2, 0, 1, 1, 0, 0};
+constexpr int kProdB[6] = {0, 2, 1, 0, 1, 0};
+
+template <int MW, int NW, int WM, int WN, int RA = STS_BF3_RA>
+__device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
+    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NWAVE = WM * WN;
+    constexpr int WIN = NT + MAX_HALO;                 // staged positions per chunk
+    constexpr int NSLOT = WIN / 32;                    // staging slots of 32 positions x 16 channels (one wave-wide load group)
+    constexpr int SPW = (NSLOT + NWAVE - 1) / NWAVE;   // slots per wave
+    constexpr int PLANE = WIN * 32, BUF = 3 * PLANE;   // bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int in_len = seg_len(a.in_seg, b);
+    const int out_len = seg_len(a.out_seg, b);
+    const int n_count = a.transposed ? in_len + a.n_extra : out_len;
+    const int n0 = bx * NT;
+    if (n0 >= n_count) return;
+    const int phase = by / mtiles;
+    const int m0 = (by - phase * mtiles) * MT;
+    const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
+    const int lo = first < last ? first : last, hi = first < last ? last : first;
+    const int W = NT + (hi - lo);
+    const int win0 = n0 + lo;
+    const int mbase = m0 + wm * MW * 32;
+    bool mvalid[MW];
+#pragma unroll
+    for (int i = 0; i < MW; i++) mvalid[i] = (mbase + i * 32) < a.Cout_pad;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; i++)
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nchunk = a.Cin_pad / CK;
+    const int nsteps = nchunk * a.ntap;
+    const int nrt = a.Cout_pad / 32;
+
+    // ---- A fragments: step s = chunk * ntap + tap is one contiguous block of nrt * 3 KB
+    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps * nrt * 3072));
+    // (the wave's row tile goes into the per-lane offset: the compiler cannot prove tid >> 6 wave-uniform and would wrap
+    // every load in a readfirstlane loop if it sat in the scalar offset)
+    const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * 3072u;
+    const unsigned a_s0 = (unsigned)phase * (unsigned)nsteps * (unsigned)nrt * 3072u;
+    const unsigned a_step = (unsigned)nrt * 3072u;
+    auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
+        const unsigned sb = a_s0 + (unsigned)s * a_step;
+#pragma unroll
+        for (int i = 0; i < MW; i++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
+    };
+    // ---- B fragments of tap j out of the staged, split window
+    const int b_t0 = wn * NW * 32 + l31 + a.tap_off - lo;
+    auto load_b = [&](int bufi, int j, u32x4 (&dst)[NW][3]) {
+        const int t = b_t0 + j * a.tap_step;
+        const unsigned char* sb = smem3 + bufi * BUF + t * 32 + ((half ^ ((t >> 3) & 1)) << 4);
+#pragma unroll
+        for (int q = 0; q < NW; q++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE + q * 1024);
+    };
+
+    // ---- input staging: wave w owns slots w, w + NWAVE, ...; lane (l31, half) of a slot holds channels 8 half .. 8 half + 7 of
+    // window position 32 slot + l31.  Raw values wait in registers (chunk c + 1 during chunk c); activation + split at store time.
+    unsigned xoff[SPW]; int lds_w[SPW]; bool sact[SPW];
+    const unsigned ld4 = (unsigned)a.x_ld * 4u;
+#pragma unroll
+    for (int i = 0; i < SPW; i++) {
+        const int slot = wave + i * NWAVE;
+        const int col = slot * 32 + l31;
+        const int pos = win0 + col;
+        sact[i] = slot < NSLOT && slot * 32 < W;                    // wave-uniform
+        const bool v = col < W && pos >= 0 && pos < in_len;
+        xoff[i] = v ? (unsigned)half * 8u * ld4 + (unsigned)pos * 4u : kOOB;
+        lds_w[i] = col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
+    }
+    float xr[SPW][8];
+    auto load_x = [&](int c) {
+        // one descriptor per chunk, based at the chunk's first row: rows ride in the scalar offset, the per-lane offset
+        // (row half + position) is range-checked by the hardware
+        const rsrc_t rs = make_rsrc(a.x + (size_t)c * CK * a.x_ld + in_base, (unsigned)((15ul * a.x_ld + in_len) * 4ul));
+#pragma unroll
+        for (int i = 0; i < SPW; i++)
+            if (sact[i]) {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)xoff[i], (int)((unsigned)e * ld4), 0));
+            }
+    };
+    auto store_tile = [&](int bufi) {
+        unsigned char* sb = smem3 + bufi * BUF;
+#pragma unroll
+        for (int i = 0; i < SPW; i++)
+            if (sact[i]) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { v[e] = xr[i][e]; if (a.in_act) v[e] = v[e] < 0.f ? v[e] * a.in_slope : v[e]; }
+                u32x4 ph, pm, pl;
+                split8(v, ph, pm, pl);
+                *(u32x4*)(sb + lds_w[i]) = ph;
+                *(u32x4*)(sb + PLANE + lds_w[i]) = pm;
+                *(u32x4*)(sb + 2 * PLANE + lds_w[i]) = pl;
+            }
+    };
+
+    // ---- main loop over steps (chunk, tap): A fragments RA - 1 steps ahead (L2), B fragments one step ahead (LDS)
+    constexpr int UNR = (RA % 2 == 0) ? RA : 2 * RA;
+    u32x4 fa[RA][MW][3], fb[2][NW][3];
+    int sj = 0, sc = 0, as = 0;
+    auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
+        const bool last_tap = sj + 1 == a.ntap;
+        int nj = sj + 1, nc = sc;
+        if (last_tap) { nj = 0; nc = sc + 1; }
+        load_a(as++, anew);               // unconditional: past the last step it reads 0 beyond the descriptor, never used
+        if (last_tap && s + 1 < nsteps) {
+            store_tile(nc & 1);           // chunk nc's tile (in registers since the start of chunk sc)
+            __syncthreads();              // tile nc visible; everyone is done reading the buffer it replaces
+            if (nc + 1 < nchunk) load_x(nc + 1);
+        }
+        load_b(nc & 1, nj, bnxt);         // past the last step: stale LDS inside the tile, never used
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int i = 0; i < MW; i++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(acur[i][kProdA[p]], bcur[q][kProdB[p]], acc[i][q]);
+        sj = nj; sc = nc;
+    };
+    load_x(0);
+    static_for<0, RA - 1>([&](auto rc) { constexpr int r = decltype(rc)::value; load_a(as++, fa[r]); });
+    store_tile(0);
+    __syncthreads();
+    load_b(0, 0, fb[0]);
+    if (nchunk > 1) load_x(1);
+    for (int s = 0; s < nsteps; s += UNR)
+        static_for<0, UNR>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (s + u < nsteps) do_step(fa[u % RA], fa[(u + RA - 1) % RA], fb[u % 2], fb[(u + 1) % 2], s + u);
+        });
+
+    // ---- epilogue on the accumulator registers (C/D layout is the one of every 32x32 MFMA:
+    // col (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+    const int out_off = a.out_off + phase;
+    if (a.epi == EPI_GATE) {
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, NW>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int n = n0 + wn * NW * 32 + q * 32 + l31;
+                const int pos = n * a.out_stride + out_off;
+                if (mvalid[i] && n < n_count && pos >= 0 && pos < out_len) {
+                    const size_t opos = out_base + (size_t)pos;
+                    static_for<0, 8>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float vt = acc[i][q][r], vs = acc[i][q][r + 8];
+                        if (a.bias) { vt += a.bias[rowp]; vs += a.bias[rowp + 16]; }
+                        if (a.ubias) { vt += a.ubias[(size_t)rowp * a.ubias_ld + b]; vs += a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b]; }
+                        const int ch = (rowp >> 5) * 16 + (rowp & 15);
+                        if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(vt) * sigmoid_ref(vs);
+                    });
+                }
+            });
+        });
+        return;
+    }
+    static_for<0, MW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, NW>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int n = n0 + wn * NW * 32 + q * 32 + l31;
+            const int pos = n * a.out_stride + out_off;
+            if (mvalid[i] && n < n_count && pos >= 0 && pos < out_len) {
+                const size_t opos = out_base + (size_t)pos;
+                static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (rowp < a.Cout) {
+                        float v = acc[i][q][r];
+                        if (a.bias) v += a.bias[rowp];
+                        if (a.ubias) v += a.ubias[(size_t)rowp * a.ubias_ld + b];
+                        epi_scalar(a, rowp, opos, v);
+                    }
+                });
+            }
+        });
+    });
+}
+
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny) {
+    const TileId t = map_tile(nx, ny, a.B);
+    if (!t.valid) return;
+    conv_bf3_body<MW, NW, WM, WN>(a, mtiles, t.bx, t.by, t.bz);
+}
+
+// grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
+    const TileId t = map_tile(nx, ny, B * G.n);
+    if (!t.valid) return;
+    const int gi = t.bz / B;
+    const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    conv_bf3_body<MW, NW, WM, WN>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline void split_host(float x, uint16_t (&p)[3]) {
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t h = u & 0xffff0000u;
+    float hf; memcpy(&hf, &h, 4);
+    const float r = x - hf;
+    uint32_t v; memcpy(&v, &r, 4);
+    const uint32_t m = v & 0xffff0000u;
+    float mf; memcpy(&mf, &m, 4);
+    const float l = r - mf;
+    uint32_t w; memcpy(&w, &l, 4);
+    p[0] = (uint16_t)(h >> 16); p[1] = (uint16_t)(m >> 16); p[2] = (uint16_t)(w >> 16);
+}
+
+size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst) {
+    const int nchunk = Cin_pad / CK, nrt = Cout_pad / 32;
+    const size_t bytes = (size_t)nphase * nchunk * ntap * nrt * 3072;
+    if (!dst) return bytes;
+    uint16_t* d = (uint16_t*)dst;
+    for (int ph = 0; ph < nphase; ph++)
+        for (int c = 0; c < nchunk; c++)
+            for (int j = 0; j < ntap; j++)
+                for (int rt = 0; rt < nrt; rt++) {
+                    uint16_t* blk = d + ((((size_t)ph * nchunk + c) * ntap + j) * nrt + rt) * 1536;   // 3 planes x 512 bf16
+                    const float* slab = wp + ((size_t)ph * ntap + j) * Cin_pad * Cout_pad;
+                    for (int l = 0; l < 64; l++) {
+                        const int i = l & 31, h = l >> 5;
+                        for (int e = 0; e < 8; e++) {
+                            uint16_t p[3];
+                            split_host(slab[(size_t)(c * CK + 8 * h + e) * Cout_pad + rt * 32 + i], p);
+                            for (int pl = 0; pl < 3; pl++) blk[pl * 512 + l * 8 + e] = p[pl];
+                        }
+                    }
+                }
+    return bytes;
+}
+
+struct Bf3Tile { int MW, NW, WM, WN; };
+static const Bf3Tile kBf3Tiles[] = {
+    {2, 2, 2, 2},  // 0: 128 x 128, 4 waves
+    {2, 2, 1, 4},  // 1:  64 x 256, 4 waves
+    {2, 2, 2, 4},  // 2: 128 x 256, 8 waves
+    {2, 2, 1, 2},  // 3:  64 x 128, 2 waves
+    {1, 2, 1, 4},  // 4:  32 x 256, 4 waves
+    {1, 2, 1, 2},  // 5:  32 x 128, 2 waves
+    {1, 4, 1, 2},  // 6:  32 x 256, 2 waves
+    {2, 4, 1, 2},  // 7:  64 x 256, 2 waves (128 accumulator registers)
+};
+constexpr int kNumBf3Tiles = 8;
+
+bool conv_bf3_eligible(const ConvArgs& a) {
+    if (!a.wb3 || a.depthwise || a.in_reflect) return false;
+    if (a.Cin != a.Cin_pad || a.Cin_pad % CK != 0 || a.Cout_pad % 32 != 0 || a.Cin < 32) return false;
+    if ((double)a.x_ld * 64.0 >= 4.0e9) return false;       // 16 rows of a chunk behind one 32-bit buffer descriptor
+    const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
+    const int halo = first < last ? last - first : first - last;
+    if (halo > MAX_HALO) return false;
+    if (a.epi == EPI_GATE && !a.gate_perm) return false;
+    if (a.epi == EPI_TANH_PCM || a.kslices > 1) return false;
+    return true;
+}
+
+static int pick_bf3_tile(int Cout_pad, long max_n, long units) {
+    // units = utterances x group members x phases
+    if (Cout_pad % 64 != 0) return 4;
+    if (Cout_pad % 128 == 0) {
+        const long n128 = (max_n + 127) / 128 * (Cout_pad / 128) * units;
+        if (n128 >= 1024) return 0;
+    }
+    const long n64 = (max_n + 127) / 128 * (Cout_pad / 64) * units;
+    return n64 >= 512 ? 3 : 3;
+}
+
+template <int MW, int NW, int WM, int WN>
+static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st) {
+    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
+    const int mt = (a.Cout_pad + MT - 1) / MT;
+    const int nx = (a.max_n + NT - 1) / NT, ny = mt * nphase;
+    const size_t lds = (size_t)6 * (NT + MAX_HALO) * 32;
+    hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * 64), lds, st, a, mt, nx, ny);
+}
+template <int MW, int NW, int WM, int WN>
+static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
+    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
+    const ConvArgs& a = G.g[0];
+    const int mt = (a.Cout_pad + MT - 1) / MT;
+    const int nx = (a.max_n + NT - 1) / NT;
+    const size_t lds = (size_t)6 * (NT + MAX_HALO) * 32;
+    hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * 64), lds, st, G,
+                       mt, a.B, nx, mt);
+}
+
+void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
+    const int nphase = a.transposed ? a.out_stride : 1;
+    if (a.max_n <= 0 || a.B <= 0) return;
+    if (tile < 0 || tile >= kNumBf3Tiles) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase);
+    switch (tile) {
+        case 0: launch_bf3<2, 2, 2, 2>(a, nphase, st); break;
+        case 1: launch_bf3<2, 2, 1, 4>(a, nphase, st); break;
+        case 2: launch_bf3<2, 2, 2, 4>(a, nphase, st); break;
+        case 3: launch_bf3<2, 2, 1, 2>(a, nphase, st); break;
+        case 4: launch_bf3<1, 2, 1, 4>(a, nphase, st); break;
+        case 5: launch_bf3<1, 2, 1, 2>(a, nphase, st); break;
+        case 6: launch_bf3<1, 4, 1, 2>(a, nphase, st); break;
+        default: launch_bf3<2, 4, 1, 2>(a, nphase, st); break;
+    }
+}
+
+bool conv_bf3_group_eligible(const ConvGroup& G) {
+    if (G.n < 1 || G.n > kMaxGroup) return false;
+    const ConvArgs& r = G.g[0];
+    for (int i = 0; i < G.n; i++) {
+        const ConvArgs& a = G.g[i];
+        if (!conv_bf3_eligible(a) || a.transposed || a.epi == EPI_GATE) return false;
+        if (a.Cout_pad != r.Cout_pad || a.max_n != r.max_n || a.B != r.B) return false;
+    }
+    return true;
+}
+
+void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
+    ConvGroup G = Gin;
+    if (G.g[0].max_n <= 0 || G.g[0].B <= 0) return;
+    for (int i = 1; i < G.n; i++)                       // longest K loop first
+        for (int j = i; j > 0 && (long)G.g[j].ntap * G.g[j].Cin_pad > (long)G.g[j - 1].ntap * G.g[j - 1].Cin_pad; j--) {
+            ConvArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
+        }
+    const ConvArgs& a = G.g[0];
+    if (tile < 0 || tile >= kNumBf3Tiles) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n);
+    switch (tile) {
+        case 0: launch_bf3_group<2, 2, 2, 2>(G, st); break;
+        case 1: launch_bf3_group<2, 2, 1, 4>(G, st); break;
+        case 2: launch_bf3_group<2, 2, 2, 4>(G, st); break;
+        case 3: launch_bf3_group<2, 2, 1, 2>(G, st); break;
+        case 4: launch_bf3_group<1, 2, 1, 4>(G, st); break;
+        case 5: launch_bf3_group<1, 2, 1, 2>(G, st); break;
+        case 6: launch_bf3_group<1, 4, 1, 2>(G, st); break;
+        default: launch_bf3_group<2, 4, 1, 2>(G, st); break;
+    }
+}
+
+}  // namespace sts

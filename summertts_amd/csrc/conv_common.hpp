@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "devmath.hpp"
 
 namespace sts {
 
@@ -57,5 +58,30 @@ __device__ __forceinline__ TileId map_tile(int nx, int ny, int nz) {
 }
 inline unsigned mapped_grid(int nx, int ny, int nz) { return (unsigned)(((long)nx * nz + 7) / 8 * 8 * ny); }
 
+// scalar epilogue shared by both kernels (everything except the gate pairing)
+__device__ __forceinline__ void epi_scalar(const ConvArgs& a, int row, size_t opos, float v) {
+    switch (a.epi) {
+        case EPI_STORE: a.y[(size_t)row * a.y_ld + opos] = v; break;
+        case EPI_RESADD: a.y[(size_t)row * a.y_ld + opos] = v + a.res[(size_t)row * a.res_ld + opos]; break;
+        case EPI_SUB: { float* p = a.y + (size_t)row * a.y_ld + opos; *p = *p - v; break; }
+        case EPI_RESSKIP: {
+            if (a.Cout != a.H && row < a.H) {
+                float* p = a.y + (size_t)row * a.y_ld + opos; *p = *p + v;
+            } else {
+                int r = a.Cout != a.H ? row - a.H : row;
+                float* p = a.aux + (size_t)r * a.aux_ld + opos;
+                *p = (a.epi_flag & 1) ? v : *p + v;
+            }
+            break;
+        }
+        case EPI_TANH_PCM: {
+            float t = tanh_ref(v);
+            if (a.aux) a.aux[opos] = t;
+            a.pcm[opos] = pcm_cast(t);
+            break;
+        }
+        default: break;
+    }
+}
 
 }  // namespace sts

@@ -91,11 +91,14 @@ void Engine::stage_begin(int s) { cur_stage_ = s; }
 void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); }
 
 // builds the kernel arguments of one conv and books its FLOPs / minimum HBM bytes
+// STS_BF3=1: decoder trunk convs on the bf16 matrix cores (split operands, conv_bf3.hip)
+static bool bf3_on() { static const bool on = getenv("STS_BF3") != nullptr && atoi(getenv("STS_BF3")) != 0; return on; }
+
 ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o, double* flops) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.x_ld = lin.ld; a.y = y; a.y_ld = lout.ld;
-    a.w = c.w; a.bias = c.bias; a.ubias = o.ubias; a.ubias_ld = lout.nb;
+    a.w = c.w; a.wb3 = c.wb3; a.bias = c.bias; a.ubias = o.ubias; a.ubias_ld = lout.nb;
     a.res = o.res; a.res_ld = o.res_ld ? o.res_ld : lout.ld;
     a.aux = o.aux; a.aux_ld = o.aux_ld ? o.aux_ld : lout.ld;
     a.pcm = o.pcm;
@@ -129,7 +132,11 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     double fl = 0;
     const ConvArgs a = conv_args(c, x, lin, y, lout, o, &fl);
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
-    if (can_mfma) {
+    if (conv_mode == 0 && bf3_on() && in_mfma_region_ && o.tile < 0 && conv_bf3_eligible(a)) {
+        mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_++;
+        static const int bt = getenv("STS_BF3_TILE") ? atoi(getenv("STS_BF3_TILE")) : -1;   // experiment knob
+        conv_bf3(a, cur_, bt);
+    } else if (can_mfma) {
         if (in_mfma_region_) { mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_++; }
         conv_mfma(a, cur_, o.tile >= 0 ? o.tile : (conv_mode >= 2 ? conv_mode - 2 : -1));
     } else {
@@ -694,7 +701,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 memset(&R, 0, sizeof(R));
                 R.n = nk; R.C = up.Cout; R.ld = l2.ld; R.slope = 0.1f; R.seg = l2.seg; R.B = l2.nb; R.max_n = l2.max_len;
                 static const int fuse_maxc = getenv("STS_FUSE_MAXC") ? atoi(getenv("STS_FUSE_MAXC")) : 128;   // experiment knob
-                bool fuse = !no_fuse && R.C <= fuse_maxc;
+                bool fuse = !no_fuse && R.C <= fuse_maxc && !bf3_on();
                 for (int j = 0; j < nk && fuse; j++) {
                     const DResBlock& rb = M.rb[(size_t)i * nk + j];
                     const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
@@ -756,6 +763,14 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                         if (conv_mfma_eligible(G1.g[j])) conv_mfma(G1.g[j], cs, gtile); else conv_generic(G1.g[j], cs);
                         if (conv_mfma_eligible(G2.g[j])) conv_mfma(G2.g[j], cs, gtile); else conv_generic(G2.g[j], cs);
                     }
+                    mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
+                    continue;
+                }
+                if (bf3_on() && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
+                    static const char* bgt = getenv("STS_BF3_GROUP_TILE");   // experiment knob: per-stage tile digits
+                    const int bt = bgt && (int)strlen(bgt) > i && bgt[i] >= '0' && bgt[i] <= '7' ? bgt[i] - '0' : -1;
+                    conv_bf3_group(G1, stream, bt);
+                    conv_bf3_group(G2, stream, bt);
                     mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
                     continue;
                 }

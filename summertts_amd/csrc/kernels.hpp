@@ -60,6 +60,9 @@ struct ConvArgs {
     int kslices; long kslice_stride;
     // optional Winograd form of the same weights (conv_wino_*): [seg][4][Cin_pad][Cout_pad], see wino_pack()
     const float* wu; int wino_n3, wino_n2;
+    // optional split-bf16 form of the same weights (conv_bf3.hip): every fp32 weight as three bf16 terms, fragment-packed by
+    // bf3_pack(); null = this conv only has the fp32 matrix-core path
+    const void* wb3;
 };
 
 // Segmented Winograd F(2,3): a k-tap filter is cut into n3 three-tap segments followed by n2 two-tap segments
@@ -158,6 +161,15 @@ void resblock_layer(const ResLayerGroup& G, hipStream_t st);
 bool resblock_wino_eligible(const ResLayerGroup& G);
 void resblock_wino(const ResLayerGroup& G, hipStream_t st);
 bool conv_group_eligible(const ConvGroup& G);
+// fp32 conv on the bf16 matrix cores: both operands split exactly into three bf16 terms (x = hi + mid + lo, 24 mantissa
+// bits), the six products of order <= 2^-16 accumulated in fp32 (conv_bf3.hip)
+bool conv_bf3_eligible(const ConvArgs& a);
+void conv_bf3(const ConvArgs& a, hipStream_t st, int tile = -1);
+bool conv_bf3_group_eligible(const ConvGroup& G);
+void conv_bf3_group(const ConvGroup& G, hipStream_t st, int tile = -1);
+// wp: packed fp32 weights [nslab][Cin_pad][Cout_pad] (nslab = taps, or phases x taps of a polyphase transposed conv)
+// -> dst: [slab-major, see conv_bf3.hip] 3 x bf16; returns the number of bytes written (dst == null: size query)
+size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst);
 void conv_mfma_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 void conv_generic(const ConvArgs& a, hipStream_t st);
 

@@ -134,6 +134,20 @@ bool pack_wino(Store& st, const HConv& h, DConv& d) {
     return true;
 }
 
+// split-bf16 copy of an already packed conv (kernels.hpp: bf3_pack) for the bf16-matrix-core kernels of conv_bf3.hip
+bool pack_bf3(Store& st, DConv& d) {
+    if (d.depthwise || d.Cin != d.Cin_pad || d.Cin < 32 || !d.w) return true;
+    const int nphase = d.transposed ? d.stride : 1, ntap = d.transposed ? d.J : d.k;
+    const size_t bytes = bf3_pack(nullptr, nphase, ntap, d.Cin_pad, d.Cout_pad, nullptr);
+    const float* dptr = nullptr;
+    float* p = st.alloc((bytes + 3) / 4 + 1024, &dptr);     // + slack: unconditional prefetches run one step past the end
+    if (!p) return false;
+    const float* wh = st.host.data() + (d.w - st.dev);
+    bf3_pack(wh, nphase, ntap, d.Cin_pad, d.Cout_pad, p);
+    d.wb3 = dptr;
+    return true;
+}
+
 // extra copy of a square 1x1 conv in the fused column-block kernel's operand order (col_layer.hip)
 bool pack_col(Store& st, const HConv& h, DConv& d, int out_rows = -1) {
     const int rows = out_rows > 0 ? out_rows : h.out_ch;
@@ -253,7 +267,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
     Reader r{blob, nfloats};
     Store st;
     // repacking pads channel counts to 16/32 and transposed convs to whole phases: bound generously
-    if (!st.init((size_t)nfloats + (size_t)nfloats / 2 + (8u << 20))) FAIL("hipMalloc of the weight store failed");
+    if (!st.init((size_t)nfloats * 3 + (8u << 20))) FAIL("hipMalloc of the weight store failed");
     m.dev_weights = st.dev;
 
     // header: /root/reference/src/models/SynthesizerTrn.cpp:103-106
@@ -338,7 +352,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         if (!r.ok || u <= 0 || k != h.k) FAIL("upsampler");
         const int pad = (int)floor((float)(k - u) / (2.0));   // header stride/padding overridden (Generator_hifigan.cpp:76-82)
         if (k - 2 * pad != u) FAIL("upsampler with (k - stride) odd is not length-preserving");
-        if (!pack_convT(st, h, u, pad, m.ups[i])) FAIL("upsampler pack");
+        if (!pack_convT(st, h, u, pad, m.ups[i]) || !pack_bf3(st, m.ups[i])) FAIL("upsampler pack");
         m.hop_total *= u;
     }
     m.rb.resize((size_t)m.n_up * m.n_resk);
@@ -346,8 +360,8 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         const int n = r.geti();
         if (!r.ok || n <= 0 || n > 32) FAIL("resblock");
         rb.c1.resize(n); rb.c2.resize(n);
-        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i]) || !pack_wino(st, h, rb.c1[i])) FAIL("resblock convs1"); }
-        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i])) FAIL("resblock convs2"); }
+        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i]) || !pack_wino(st, h, rb.c1[i]) || !pack_bf3(st, rb.c1[i])) FAIL("resblock convs1"); }
+        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i]) || !pack_bf3(st, rb.c2[i])) FAIL("resblock convs2"); }
     }
     { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_post)) FAIL("conv_post"); }
     if (m.dec_type == 0 && m.is_ms == 1) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.dec_cond)) FAIL("decoder cond"); }

@@ -62,6 +62,44 @@ def test_conv_kernels_against_torch_fp32(case):
     assert np.array_equal(y, y1)
 
 
+BF3_CASES = [c for c in CONV_CASES if not c[7] and c[0] >= 32 and c[0] % 16 == 0 and c[1] >= 32] + [
+    (512, 256, 16, 4, 1, 70, 8, False), (128, 96, 3, 1, 1, 4000, 0, False), (32, 32, 7, 9, 3, 5000, 0, False)]
+
+
+@pytest.mark.parametrize("case", BF3_CASES, ids=str)
+def test_bf3_conv_is_as_accurate_as_the_fp32_matrix_core_kernel(case):
+    """Split-bf16 conv (conv_bf3.hip: fp32 operands as 3 bf16 terms, 6 products, fp32 accumulate) against a float64
+    convolution: same 2e-5 bound as the fp32 kernels, and an RMS error no worse than 1.5x the exact-fp32 MFMA kernel's."""
+    import torch
+    import torch.nn.functional as F
+    ci, co, k, pad, dil, L, st, dw = case
+    rng = np.random.default_rng(ci * 977 + co + k)
+    x = (rng.standard_normal((ci, L)) * rng.uniform(0.05, 3.0, (ci, 1))).astype(np.float32)
+    w = (rng.standard_normal((co, k, ci)) / np.sqrt(k * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    xt = torch.from_numpy(x).double()[None]
+    if st:
+        ref = F.conv_transpose1d(xt, torch.from_numpy(w).double().permute(2, 0, 1).contiguous(), torch.from_numpy(b).double(), stride=st, padding=pad)[0].numpy()
+    else:
+        ref = F.conv1d(xt, torch.from_numpy(w).double().permute(0, 2, 1).contiguous(), torch.from_numpy(b).double(), padding=pad, dilation=dil)[0].numpy()
+    y32 = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=2 + 4)          # exact-fp32 MFMA kernel, 32 x 128 tile
+    e32 = np.sqrt(np.mean((y32 - ref) ** 2))
+    outs = []
+    for mode in (13, 20, 21, 22, 23, 24, 25, 26):
+        y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=mode)
+        assert y.shape == ref.shape
+        err = np.abs(y - ref)
+        assert err.max() <= 2e-5, (case, mode, err.max())
+        assert np.sqrt(np.mean(err ** 2)) <= 1.5 * e32 + 1e-9, (case, mode, np.sqrt(np.mean(err ** 2)), e32)
+        outs.append(y)
+    for y in outs[1:]:     # every tile shape walks K in the same order
+        assert np.array_equal(y, outs[0]), case
+    # fused input leaky-relu is applied before the split
+    y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=13)
+    y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=13)
+    assert np.array_equal(y, y1)
+
+
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1])
 def test_hip_matches_reference_golden(path):
     g, cfg, blob = load_golden(path)

@@ -20,7 +20,11 @@ SHAPES = [  # name, Cin, Cout, k, dil, L, stride_t
     ("mbb_s2_k3", 128, 128, 3, 1, 16 * F, 0), ("mbb_s2_k11d5", 128, 128, 11, 5, 16 * F, 0),
     ("s4_k3", 32, 32, 3, 1, 256 * F, 0), ("s4_k7d3", 32, 32, 7, 3, 256 * F, 0), ("s4_k11d5", 32, 32, 11, 5, 256 * F, 0),
 ]
-MODES = {12: "wino", 0: "auto", 2: "128x128", 3: "64x256", 4: "32x512", 5: "64x128", 6: "32x128", 7: "32x256", 8: "splitk32", 9: "splitk64"}
+if os.environ.get("CONV_BENCH_MODES"):
+    _only_modes = [int(v) for v in os.environ["CONV_BENCH_MODES"].split(",")]
+else:
+    _only_modes = None
+MODES = {13: "bf3", 20: "bf3_128x128", 21: "bf3_64x256", 22: "bf3_128x256w8", 23: "bf3_64x128", 24: "bf3_32x256", 25: "bf3_32x128", 26: "bf3_32x256w2", 27: "bf3_64x256w2", 12: "wino", 0: "auto", 2: "128x128", 3: "64x256", 4: "32x512", 5: "64x128", 6: "32x128", 7: "32x256", 8: "splitk32", 9: "splitk64"}
 
 def main():
     only = sys.argv[1:] if len(sys.argv) > 1 else None
@@ -35,6 +39,8 @@ def main():
         flops = 2.0 * ci * co * k * L
         line = f"{name:14s} Cin={ci:4d} Cout={co:4d} k={k:2d} d={dil} L={L:7d} {flops/1e9:8.2f} GFLOP |"
         for mode, mname in MODES.items():
+            if _only_modes is not None and mode not in _only_modes:
+                continue
             if co % 64 and mode in ():
                 continue
             try:
