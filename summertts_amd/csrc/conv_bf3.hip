@@ -63,13 +63,16 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 constexpr int kProdA[6] = {2, 0, 1, 1, 0, 0};
 constexpr int kProdB[6] = {0, 2, 1, 0, 1, 0};
 
-template <int MW, int NW, int WM, int WN, int RA = STS_BF3_RA>
+template <int MW, int NW, int WM, int WN, int NSUB = 1, int RA = STS_BF3_RA>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
+    // NSUB: 16-channel sub-chunks staged per barrier (a staged chunk = 16 NSUB channels): fewer barriers and more bytes in
+    // flight per workgroup for the few-tap convs, at NSUB x the staging registers and LDS
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NWAVE = WM * WN;
     constexpr int WIN = NT + MAX_HALO;                 // staged positions per chunk
     constexpr int NSLOT = WIN / 32;                    // staging slots of 32 positions x 16 channels (one wave-wide load group)
-    constexpr int SPW = (NSLOT + NWAVE - 1) / NWAVE;   // slots per wave
-    constexpr int PLANE = WIN * 32, BUF = 3 * PLANE;   // bytes
+    constexpr int NITEM = NSLOT * NSUB;                // (sub-chunk, slot) items per staged chunk
+    constexpr int SPW = (NITEM + NWAVE - 1) / NWAVE;   // items per wave
+    constexpr int PLANE = WIN * 32, SUB = 3 * PLANE, BUF = NSUB * SUB;   // bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int in_len = seg_len(a.in_seg, b);
     const int out_len = seg_len(a.out_seg, b);
@@ -80,6 +83,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     const int m0 = (by - phase * mtiles) * MT;
     const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
@@ -100,11 +104,11 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int nchunk = a.Cin_pad / CK;
-    const int nsteps = nchunk * a.ntap;
+    const int nchunk = a.Cin_pad / (CK * NSUB);
+    const int nsteps = nchunk * NSUB * a.ntap;
     const int nrt = a.Cout_pad / 32;
 
-    // ---- A fragments: step s = chunk * ntap + tap is one contiguous block of nrt * 3 KB
+    // ---- A fragments: step s = (16-channel chunk) * ntap + tap is one contiguous block of nrt * 3 KB
     const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps * nrt * 3072));
     // (the wave's row tile goes into the per-lane offset: the compiler cannot prove tid >> 6 wave-uniform and would wrap
     // every load in a readfirstlane loop if it sat in the scalar offset)
@@ -119,39 +123,42 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             for (int pl = 0; pl < 3; pl++)
                 dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
     };
-    // ---- B fragments of tap j out of the staged, split window
+    // ---- B fragments of (sub-chunk, tap j) out of the staged, split window
     const int b_t0 = wn * NW * 32 + l31 + a.tap_off - lo;
-    auto load_b = [&](int bufi, int j, u32x4 (&dst)[NW][3]) {
+    auto load_b = [&](int bufi, int sub, int j, u32x4 (&dst)[NW][3]) {
         const int t = b_t0 + j * a.tap_step;
-        const unsigned char* sb = smem3 + bufi * BUF + t * 32 + ((half ^ ((t >> 3) & 1)) << 4);
+        const unsigned char* sb = smem3 + bufi * BUF + sub * SUB + t * 32 + ((half ^ ((t >> 3) & 1)) << 4);
 #pragma unroll
         for (int q = 0; q < NW; q++)
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE + q * 1024);
     };
 
-    // ---- input staging: wave w owns slots w, w + NWAVE, ...; lane (l31, half) of a slot holds channels 8 half .. 8 half + 7 of
-    // window position 32 slot + l31.  Raw values wait in registers (chunk c + 1 during chunk c); activation + split at store time.
-    unsigned xoff[SPW]; int lds_w[SPW]; bool sact[SPW];
+    // ---- input staging: wave w owns items w, w + NWAVE, ... of a chunk; item = (sub-chunk, slot); lane (l31, half) of an item
+    // holds channels 8 half .. 8 half + 7 of window position 32 slot + l31.  Raw values wait in registers (chunk c + 1 during
+    // chunk c); activation + split at store time.
+    unsigned xoff[SPW]; int lds_w[SPW]; int isub[SPW]; bool sact[SPW];
     const unsigned ld4 = (unsigned)a.x_ld * 4u;
 #pragma unroll
     for (int i = 0; i < SPW; i++) {
-        const int slot = wave + i * NWAVE;
+        const int it = swave + i * NWAVE;                           // wave-uniform
+        const int sub = it / NSLOT, slot = it - sub * NSLOT;
         const int col = slot * 32 + l31;
         const int pos = win0 + col;
-        sact[i] = slot < NSLOT && slot * 32 < W;                    // wave-uniform
+        isub[i] = sub;
+        sact[i] = it < NITEM && slot * 32 < W;
         const bool v = col < W && pos >= 0 && pos < in_len;
         xoff[i] = v ? (unsigned)half * 8u * ld4 + (unsigned)pos * 4u : kOOB;
-        lds_w[i] = col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
+        lds_w[i] = sub * SUB + col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
     }
     float xr[SPW][8];
     auto load_x = [&](int c) {
-        // one descriptor per chunk, based at the chunk's first row: rows ride in the scalar offset, the per-lane offset
-        // (row half + position) is range-checked by the hardware
-        const rsrc_t rs = make_rsrc(a.x + (size_t)c * CK * a.x_ld + in_base, (unsigned)((15ul * a.x_ld + in_len) * 4ul));
+        // one descriptor per 16-channel sub-chunk, based at its first row: rows ride in the scalar offset, the per-lane
+        // offset (row half + position) is range-checked by the hardware
 #pragma unroll
         for (int i = 0; i < SPW; i++)
             if (sact[i]) {
+                const rsrc_t rs = make_rsrc(a.x + (size_t)(c * NSUB + isub[i]) * CK * a.x_ld + in_base, (unsigned)((15ul * a.x_ld + in_len) * 4ul));
 #pragma unroll
                 for (int e = 0; e < 8; e++)
                     xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)xoff[i], (int)((unsigned)e * ld4), 0));
@@ -173,34 +180,34 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             }
     };
 
-    // ---- main loop over steps (chunk, tap): A fragments RA - 1 steps ahead (L2), B fragments one step ahead (LDS)
+    // ---- main loop over steps (chunk, sub-chunk, tap): A fragments RA - 1 steps ahead (L2), B fragments one step ahead (LDS)
     constexpr int UNR = (RA % 2 == 0) ? RA : 2 * RA;
     u32x4 fa[RA][MW][3], fb[2][NW][3];
-    int sj = 0, sc = 0, as = 0;
+    int sj = 0, ssub = 0, sc = 0, as = 0;
     auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
-        const bool last_tap = sj + 1 == a.ntap;
-        int nj = sj + 1, nc = sc;
-        if (last_tap) { nj = 0; nc = sc + 1; }
+        int nj = sj + 1, nsub = ssub, nc = sc;
+        if (nj == a.ntap) { nj = 0; nsub = ssub + 1; if (nsub == NSUB) { nsub = 0; nc = sc + 1; } }
         load_a(as++, anew);               // unconditional: past the last step it reads 0 beyond the descriptor, never used
-        if (last_tap && s + 1 < nsteps) {
+        if (nc != sc && s + 1 < nsteps) {
             store_tile(nc & 1);           // chunk nc's tile (in registers since the start of chunk sc)
             __syncthreads();              // tile nc visible; everyone is done reading the buffer it replaces
             if (nc + 1 < nchunk) load_x(nc + 1);
         }
-        load_b(nc & 1, nj, bnxt);         // past the last step: stale LDS inside the tile, never used
+        load_b(nc & 1, nsub, nj, bnxt);   // past the last step: stale LDS inside the tile, never used
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 6; p++)
 #pragma unroll
             for (int i = 0; i < MW; i++)
 #pragma unroll
                 for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(acur[i][kProdA[p]], bcur[q][kProdB[p]], acc[i][q]);
-        sj = nj; sc = nc;
+        sj = nj; ssub = nsub; sc = nc;
     };
     load_x(0);
     static_for<0, RA - 1>([&](auto rc) { constexpr int r = decltype(rc)::value; load_a(as++, fa[r]); });
     store_tile(0);
     __syncthreads();
-    load_b(0, 0, fb[0]);
+    load_b(0, 0, 0, fb[0]);
     if (nchunk > 1) load_x(1);
     for (int s = 0; s < nsteps; s += UNR)
         static_for<0, UNR>([&](auto uc) {
@@ -257,21 +264,245 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     });
 }
 
-template <int MW, int NW, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny) {
+template <int MW, int NW, int WM, int WN, int NSUB>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny) {
     const TileId t = map_tile(nx, ny, a.B);
     if (!t.valid) return;
-    conv_bf3_body<MW, NW, WM, WN>(a, mtiles, t.bx, t.by, t.bz);
+    conv_bf3_body<MW, NW, WM, WN, NSUB>(a, mtiles, t.bx, t.by, t.bz);
 }
 
 // grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
-template <int MW, int NW, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
+template <int MW, int NW, int WM, int WN, int NSUB>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
     const TileId t = map_tile(nx, ny, B * G.n);
     if (!t.valid) return;
     const int gi = t.bz / B;
     const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_bf3_body<MW, NW, WM, WN>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
+    conv_bf3_body<MW, NW, WM, WN, NSUB>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused ResBlock layer on the bf16 matrix cores (C = 32 MW WM <= 64)
+//   y = x + conv2_{k2,d=1}( lrelu( conv1_{k1,d1}( lrelu(x) ) ) )        (ResBlock1.cpp:55-69, one dilation)
+// With the matrix time cut to 6/16 these narrow stages are HBM-bound unless the intermediate stays on chip, and
+// latency-bound unless a workgroup keeps many loads in flight.  So: the workgroup stages its WHOLE input window
+// (all C channels x (P1 + 2 h1) positions), split, in one go -- every load of the tile is issued before the first
+// is consumed, one barrier -- runs conv1 on P1 = 32 NW WN columns without another barrier, parks the biased,
+// activated, zero-padded and split intermediate in LDS over the (dead) input window, and runs conv2 out of it.
+// The intermediate is parked in the k order the accumulator layout gives for free (a lane holds rows 4 h + {0..3} and
+// 8 + 4 h + {0..3} of every 16-row block = one 16-byte unit per plane); conv2's weights are packed to match (perm_k).
+// ------------------------------------------------------------------------------------------------
+template <int MW, int WM, int NW, int WN>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_bf3_kernel(ResLayerGroup G, int nx, int wst) {
+    constexpr int C = 32 * MW * WM, NCH = C / 16, NRT = C / 32, NWAVE = WM * WN, P1 = 32 * NW * WN;
+    constexpr int PLANE2 = P1 * 32, CHUNK2 = 3 * PLANE2;
+    constexpr int MAXSLOT = (P1 + MAX_HALO) / 32;
+    constexpr int ITEMS = (NCH * MAXSLOT + NWAVE - 1) / NWAVE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const TileId t = map_tile(nx, 1, G.B * G.n);
+    if (!t.valid) return;
+    const int gi = t.bz / G.B, b = t.bz - gi * G.B;
+    const ResLayerArgs& a = ((const ResLayerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[gi];
+    const int d = a.dil1;
+    const int h1 = d * (a.k1 - 1) / 2, h2 = (a.k2 - 1) / 2;
+    const int NT = P1 - 2 * h2;
+    const int len = seg_len(G.seg, b);
+    const int n0 = t.bx * NT;
+    if (n0 >= len) return;
+    const size_t base = (size_t)seg_start(G.seg, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const int wn = wave % WN, wm = wave / WN;
+    const int mbase = wm * MW * 32;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int W1 = P1 + 2 * h1, nslot = (W1 + 31) >> 5;
+    const int w0 = n0 - h2 - h1;
+    const int plane1 = wst * 32, chunk1 = 3 * plane1;
+    const unsigned ld4 = (unsigned)G.ld * 4u;
+
+    // ---- stage the whole window: item t = (chunk, slot of 32 positions), wave w owns items w, w + NWAVE, ...
+    {
+        float xr[ITEMS][8];
+        int lw[ITEMS];
+        const int nitem = NCH * nslot;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int it = swave + i * NWAVE;           // wave-uniform (scalar)
+            const int c = it / nslot, sl = it - c * nslot;
+            const int col = sl * 32 + l31, pos = w0 + col;
+            const bool v = col < W1 && pos >= 0 && pos < len;
+            const unsigned voff = v ? (unsigned)half * 8u * ld4 + (unsigned)pos * 4u : kOOB;
+            lw[i] = c * chunk1 + col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
+            if (it < nitem) {
+                const rsrc_t rs = make_rsrc(a.x + (size_t)c * CK * G.ld + base, (unsigned)((15ul * G.ld + len) * 4ul));
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((unsigned)e * ld4), 0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int it = swave + i * NWAVE;
+            if (it < nitem) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = xr[i][e] < 0.f ? xr[i][e] * G.slope : xr[i][e];
+                u32x4 ph, pm, pl;
+                split8(v, ph, pm, pl);
+                *(u32x4*)(smem3 + lw[i]) = ph;
+                *(u32x4*)(smem3 + plane1 + lw[i]) = pm;
+                *(u32x4*)(smem3 + 2 * plane1 + lw[i]) = pl;
+            }
+        }
+    }
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; i++)
+#pragma unroll
+        for (int q = 0; q < NW; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][q][r] = 0.f;
+    const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * 3072u;
+    u32x4 fa[2][MW][3], fb[2][NW][3];
+    auto mfmas = [&](u32x4 (&ac)[MW][3], u32x4 (&bc)[NW][3]) {
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int i = 0; i < MW; i++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(ac[i][kProdA[p]], bc[q][kProdB[p]], acc[i][q]);
+    };
+    __syncthreads();
+
+    // ================= phase 1: conv1 on the P1 columns [n0 - h2, n0 - h2 + P1) =================
+    {
+        const int nsteps = NCH * a.k1;
+        const rsrc_t wrs = make_rsrc(a.wb1, (unsigned)(nsteps * NRT * 3072));
+        auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
+            const unsigned sb = (unsigned)s * (unsigned)(NRT * 3072);
+#pragma unroll
+            for (int i = 0; i < MW; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
+        };
+        const int p0 = wn * NW * 32 + l31;
+        auto load_b = [&](int c, int j, u32x4 (&dst)[NW][3]) {
+            const int p = p0 + j * d;
+            const unsigned char* sb = smem3 + c * chunk1 + p * 32 + ((half ^ ((p >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < NW; q++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * plane1 + q * 1024);
+        };
+        int sj = 0, sc = 0;
+        load_a(0, fa[0]);
+        load_b(0, 0, fb[0]);
+        for (int s = 0; s < nsteps; s += 2)
+            static_for<0, 2>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if (s + u < nsteps) {
+                    int nj = sj + 1, nc = sc;
+                    if (nj == a.k1) { nj = 0; nc = sc + 1; }
+                    load_a(s + u + 1, fa[(u + 1) % 2]);                       // past the end: zeros beyond the descriptor
+                    load_b(nc < NCH ? nc : 0, nj, fb[(u + 1) % 2]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs (the scheduler would sink them)
+                    mfmas(fa[u % 2], fb[u % 2]);
+                    sj = nj; sc = nc;
+                }
+            });
+    }
+    __syncthreads();          // every wave is done reading the staged window (the parked intermediate overwrites it)
+    // ---- park: bias, conv2's input activation, conv2's zero padding outside [0, len), split
+    static_for<0, MW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, NW>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int col = wn * NW * 32 + q * 32 + l31;
+            const int pos = n0 - h2 + col;
+            const bool inside = pos >= 0 && pos < len;
+            static_for<0, 2>([&](auto hc) {
+                constexpr int hh = decltype(hc)::value;       // 16-row block of the 32-row tile
+                const int cc = (mbase >> 4) + 2 * i + hh;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int row = mbase + i * 32 + hh * 16 + 8 * (e >> 2) + 4 * half + (e & 3);
+                    float t1 = acc[i][q][hh * 8 + e];
+                    if (a.b1) t1 += a.b1[row];
+                    t1 = t1 < 0.f ? t1 * G.slope : t1;
+                    v[e] = inside ? t1 : 0.f;
+                    acc[i][q][hh * 8 + e] = 0.f;
+                }
+                u32x4 ph, pm, pl;
+                split8(v, ph, pm, pl);
+                unsigned char* dst = smem3 + cc * CHUNK2 + col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
+                *(u32x4*)(dst) = ph;
+                *(u32x4*)(dst + PLANE2) = pm;
+                *(u32x4*)(dst + 2 * PLANE2) = pl;
+            });
+        });
+    });
+    __syncthreads();
+
+    // ================= phase 2: conv2 (dilation 1) out of the parked intermediate =================
+    {
+        const int nsteps = NCH * a.k2;
+        const rsrc_t wrs = make_rsrc(a.wb2, (unsigned)(nsteps * NRT * 3072));
+        auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
+            const unsigned sb = (unsigned)s * (unsigned)(NRT * 3072);
+#pragma unroll
+            for (int i = 0; i < MW; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
+        };
+        const int p0 = wn * NW * 32 + l31;
+        auto load_b = [&](int c, int j, u32x4 (&dst)[NW][3]) {
+            const int p = p0 + j;
+            const unsigned char* sb = smem3 + c * CHUNK2 + p * 32 + ((half ^ ((p >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < NW; q++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE2 + q * 1024);
+        };
+        int sj = 0, sc = 0;
+        load_a(0, fa[0]);
+        load_b(0, 0, fb[0]);
+        for (int s = 0; s < nsteps; s += 2)
+            static_for<0, 2>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if (s + u < nsteps) {
+                    int nj = sj + 1, nc = sc;
+                    if (nj == a.k2) { nj = 0; nc = sc + 1; }
+                    load_a(s + u + 1, fa[(u + 1) % 2]);
+                    load_b(nc < NCH ? nc : 0, nj, fb[(u + 1) % 2]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs (the scheduler would sink them)
+                    mfmas(fa[u % 2], fb[u % 2]);
+                    sj = nj; sc = nc;
+                }
+            });
+    }
+    // ---- epilogue: + b2 + x (the residual is re-read: the staged copy was activated and split)
+    static_for<0, MW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, NW>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int col = wn * NW * 32 + q * 32 + l31;
+            const int pos = n0 + col;
+            if (col < NT && pos < len) {
+                const size_t opos = base + (size_t)pos;
+                static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][q][r];
+                    if (a.b2) v += a.b2[row];
+                    a.y[(size_t)row * G.ld + opos] = v + a.x[(size_t)row * G.ld + opos];
+                });
+            }
+        });
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -290,7 +521,7 @@ static inline void split_host(float x, uint16_t (&p)[3]) {
     p[0] = (uint16_t)(h >> 16); p[1] = (uint16_t)(m >> 16); p[2] = (uint16_t)(w >> 16);
 }
 
-size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst) {
+size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst, bool perm_k) {
     const int nchunk = Cin_pad / CK, nrt = Cout_pad / 32;
     const size_t bytes = (size_t)nphase * nchunk * ntap * nrt * 3072;
     if (!dst) return bytes;
@@ -305,7 +536,8 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
                         const int i = l & 31, h = l >> 5;
                         for (int e = 0; e < 8; e++) {
                             uint16_t p[3];
-                            split_host(slab[(size_t)(c * CK + 8 * h + e) * Cout_pad + rt * 32 + i], p);
+                            const int ci = perm_k ? 8 * (e >> 2) + 4 * h + (e & 3) : 8 * h + e;
+                            split_host(slab[(size_t)(c * CK + ci) * Cout_pad + rt * 32 + i], p);
                             for (int pl = 0; pl < 3; pl++) blk[pl * 512 + l * 8 + e] = p[pl];
                         }
                     }
@@ -313,18 +545,11 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
     return bytes;
 }
 
-struct Bf3Tile { int MW, NW, WM, WN; };
-static const Bf3Tile kBf3Tiles[] = {
-    {2, 2, 2, 2},  // 0: 128 x 128, 4 waves
-    {2, 2, 1, 4},  // 1:  64 x 256, 4 waves
-    {2, 2, 2, 4},  // 2: 128 x 256, 8 waves
-    {2, 2, 1, 2},  // 3:  64 x 128, 2 waves
-    {1, 2, 1, 4},  // 4:  32 x 256, 4 waves
-    {1, 2, 1, 2},  // 5:  32 x 128, 2 waves
-    {1, 4, 1, 2},  // 6:  32 x 256, 2 waves
-    {2, 4, 1, 2},  // 7:  64 x 256, 2 waves (128 accumulator registers)
-};
-constexpr int kNumBf3Tiles = 8;
+// tile codes: t = 0..5 below with 16-channel chunks, 8 + t the same tile with 32-channel chunks (NSUB = 2)
+//   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
+//   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
+constexpr int kNumBf3Tiles = 6;
+static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
     if (!a.wb3 || a.depthwise || a.in_reflect) return false;
@@ -349,38 +574,43 @@ static int pick_bf3_tile(int Cout_pad, long max_n, long units) {
     return n64 >= 512 ? 3 : 3;
 }
 
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int NSUB>
 static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT, ny = mt * nphase;
-    const size_t lds = (size_t)6 * (NT + MAX_HALO) * 32;
-    hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * 64), lds, st, a, mt, nx, ny);
+    const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
+    hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * 64), lds, st, a, mt, nx, ny);
 }
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int NSUB>
 static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     const ConvArgs& a = G.g[0];
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT;
-    const size_t lds = (size_t)6 * (NT + MAX_HALO) * 32;
-    hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * 64), lds, st, G,
+    const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
+    hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * 64), lds, st, G,
                        mt, a.B, nx, mt);
 }
 
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     const int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
-    if (tile < 0 || tile >= kNumBf3Tiles) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase);
+    if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase);
+    if (tile >= 8 && a.Cin_pad % 32 != 0) tile -= 8;
     switch (tile) {
-        case 0: launch_bf3<2, 2, 2, 2>(a, nphase, st); break;
-        case 1: launch_bf3<2, 2, 1, 4>(a, nphase, st); break;
-        case 2: launch_bf3<2, 2, 2, 4>(a, nphase, st); break;
-        case 3: launch_bf3<2, 2, 1, 2>(a, nphase, st); break;
-        case 4: launch_bf3<1, 2, 1, 4>(a, nphase, st); break;
-        case 5: launch_bf3<1, 2, 1, 2>(a, nphase, st); break;
-        case 6: launch_bf3<1, 4, 1, 2>(a, nphase, st); break;
-        default: launch_bf3<2, 4, 1, 2>(a, nphase, st); break;
+        case 0: launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
+        case 1: launch_bf3<2, 2, 1, 4, 1>(a, nphase, st); break;
+        case 2: launch_bf3<2, 2, 2, 4, 1>(a, nphase, st); break;
+        case 3: launch_bf3<2, 2, 1, 2, 1>(a, nphase, st); break;
+        case 4: launch_bf3<1, 2, 1, 4, 1>(a, nphase, st); break;
+        case 5: launch_bf3<1, 2, 1, 2, 1>(a, nphase, st); break;
+        case 8: launch_bf3<2, 2, 2, 2, 2>(a, nphase, st); break;
+        case 9: launch_bf3<2, 2, 1, 4, 2>(a, nphase, st); break;
+        case 10: launch_bf3<2, 2, 2, 4, 2>(a, nphase, st); break;
+        case 11: launch_bf3<2, 2, 1, 2, 2>(a, nphase, st); break;
+        case 12: launch_bf3<1, 2, 1, 4, 2>(a, nphase, st); break;
+        default: launch_bf3<1, 2, 1, 2, 2>(a, nphase, st); break;
     }
 }
 
@@ -403,16 +633,65 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
             ConvArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
         }
     const ConvArgs& a = G.g[0];
-    if (tile < 0 || tile >= kNumBf3Tiles) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n);
+    if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n);
+    if (tile >= 8) for (int i = 0; i < G.n; i++) if (G.g[i].Cin_pad % 32 != 0) { tile -= 8; break; }
     switch (tile) {
-        case 0: launch_bf3_group<2, 2, 2, 2>(G, st); break;
-        case 1: launch_bf3_group<2, 2, 1, 4>(G, st); break;
-        case 2: launch_bf3_group<2, 2, 2, 4>(G, st); break;
-        case 3: launch_bf3_group<2, 2, 1, 2>(G, st); break;
-        case 4: launch_bf3_group<1, 2, 1, 4>(G, st); break;
-        case 5: launch_bf3_group<1, 2, 1, 2>(G, st); break;
-        case 6: launch_bf3_group<1, 4, 1, 2>(G, st); break;
-        default: launch_bf3_group<2, 4, 1, 2>(G, st); break;
+        case 0: launch_bf3_group<2, 2, 2, 2, 1>(G, st); break;
+        case 1: launch_bf3_group<2, 2, 1, 4, 1>(G, st); break;
+        case 2: launch_bf3_group<2, 2, 2, 4, 1>(G, st); break;
+        case 3: launch_bf3_group<2, 2, 1, 2, 1>(G, st); break;
+        case 4: launch_bf3_group<1, 2, 1, 4, 1>(G, st); break;
+        case 5: launch_bf3_group<1, 2, 1, 2, 1>(G, st); break;
+        case 8: launch_bf3_group<2, 2, 2, 2, 2>(G, st); break;
+        case 9: launch_bf3_group<2, 2, 1, 4, 2>(G, st); break;
+        case 10: launch_bf3_group<2, 2, 2, 4, 2>(G, st); break;
+        case 11: launch_bf3_group<2, 2, 1, 2, 2>(G, st); break;
+        case 12: launch_bf3_group<1, 2, 1, 4, 2>(G, st); break;
+        default: launch_bf3_group<1, 2, 1, 2, 2>(G, st); break;
+    }
+}
+
+bool resblock_bf3_eligible(const ResLayerGroup& G) {
+    if (G.n < 1 || G.n > kMaxGroup || (G.C != 32 && G.C != 64) || G.max_n <= 0 || G.B <= 0) return false;
+    if ((double)G.ld * 64.0 >= 4.0e9) return false;
+    for (int i = 0; i < G.n; i++) {
+        const ResLayerArgs& a = G.g[i];
+        if (!a.wb1 || !a.wb2 || !(a.k1 & 1) || !(a.k2 & 1) || a.k1 < 1 || a.k2 < 1) return false;
+        if (a.dil1 < 1 || a.dil1 * (a.k1 - 1) > MAX_HALO || a.k2 - 1 > 32) return false;
+        if (a.x == a.y) return false;
+    }
+    return true;
+}
+
+template <int MW, int WM, int NW, int WN>
+static void launch_resblock_bf3(const ResLayerGroup& G, hipStream_t st) {
+    constexpr int C = 32 * MW * WM, P1 = 32 * NW * WN;
+    int nx = 0, halo = 0;
+    for (int i = 0; i < G.n; i++) {
+        const int NT = P1 - (G.g[i].k2 - 1);
+        const int n = (G.max_n + NT - 1) / NT;
+        if (n > nx) nx = n;
+        const int h = G.g[i].dil1 * (G.g[i].k1 - 1);
+        if (h > halo) halo = h;
+    }
+    const int wst = (P1 + halo + 31) / 32 * 32;
+    const size_t stage = (size_t)C * wst * 6, park = (size_t)C * P1 * 6 + 1024;    // + slack: conv2's taps of the discarded last columns
+    const size_t lds = stage > park ? stage : park;
+    hipLaunchKernelGGL((resblock_bf3_kernel<MW, WM, NW, WN>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx, wst);
+}
+
+// variant: -1 automatic; C = 64: 0 = (32 x 64 per wave, 2 x 2 waves), 1 = (64 x 64 per wave, 1 x 2 waves);
+//          C = 32: 0 = 4 waves x 64 columns (P1 = 256), 1 = 2 waves x 64 columns (P1 = 128)
+void resblock_bf3(const ResLayerGroup& Gin, hipStream_t st, int variant) {
+    ResLayerGroup G = Gin;
+    for (int i = 1; i < G.n; i++)                       // longest K loops first
+        for (int j = i; j > 0 && G.g[j].k1 + G.g[j].k2 > G.g[j - 1].k1 + G.g[j - 1].k2; j--) {
+            ResLayerArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
+        }
+    if (G.C == 64) {
+        if (variant == 1) launch_resblock_bf3<2, 1, 2, 2>(G, st); else launch_resblock_bf3<1, 2, 2, 2>(G, st);
+    } else {
+        if (variant == 1) launch_resblock_bf3<1, 1, 2, 2>(G, st); else launch_resblock_bf3<1, 1, 2, 4>(G, st);
     }
 }
 

@@ -701,7 +701,10 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 memset(&R, 0, sizeof(R));
                 R.n = nk; R.C = up.Cout; R.ld = l2.ld; R.slope = 0.1f; R.seg = l2.seg; R.B = l2.nb; R.max_n = l2.max_len;
                 static const int fuse_maxc = getenv("STS_FUSE_MAXC") ? atoi(getenv("STS_FUSE_MAXC")) : 128;   // experiment knob
-                bool fuse = !no_fuse && R.C <= fuse_maxc && !bf3_on();
+                bool fuse = !no_fuse && R.C <= fuse_maxc;
+                static const bool bf3_nofuse = getenv("STS_BF3_NOFUSE") != nullptr;   // experiment knob
+                const bool bf3_layer = bf3_on() && !bf3_nofuse;
+                if (bf3_on() && (R.C > 64 || bf3_nofuse)) fuse = false;
                 for (int j = 0; j < nk && fuse; j++) {
                     const DResBlock& rb = M.rb[(size_t)i * nk + j];
                     const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
@@ -713,6 +716,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     float* nxt = (cur[j] == pa) ? pb : pa;
                     R.g[j].x = cur[j]; R.g[j].y = nxt; R.g[j].w1 = c1.w; R.g[j].b1 = c1.bias; R.g[j].w2 = c2.w; R.g[j].b2 = c2.bias;
                     R.g[j].k1 = c1.k; R.g[j].dil1 = c1.dil; R.g[j].k2 = c2.k; R.g[j].wu1 = c1.wu; R.g[j].wu2 = c2.wu;
+                    R.g[j].wb1 = c1.wb3; R.g[j].wb2 = c2.wb3p;
                 }
                 // the 128-channel variant runs 8-wave workgroups, two per CU: only worth it when the grid fills the chip twice
                 if (fuse && R.C > 64) fuse = (long)((l2.max_len + 117) / 118) * l2.nb * nk >= 512;
@@ -731,6 +735,12 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     // the direct-form fused kernel otherwise
                     static const bool no_wino = getenv("STS_NO_WINO") != nullptr;   // experiment knob
                     const bool wino = !no_wino && resblock_wino_eligible(R);
+                    if (bf3_layer && resblock_bf3_eligible(R)) {
+                        static const int bv = getenv("STS_BF3_LAYER_VARIANT") ? atoi(getenv("STS_BF3_LAYER_VARIANT")) : -1;   // experiment knob
+                        resblock_bf3(R, stream, bv);
+                        mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_ += 1;
+                        continue;
+                    }
                     if (per_chain) {
                         for (int j = 0; j < nk; j++) {
                             ResLayerGroup R1 = R; R1.n = 1; R1.g[0] = R.g[j];
@@ -768,7 +778,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 }
                 if (bf3_on() && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
                     static const char* bgt = getenv("STS_BF3_GROUP_TILE");   // experiment knob: per-stage tile digits
-                    const int bt = bgt && (int)strlen(bgt) > i && bgt[i] >= '0' && bgt[i] <= '7' ? bgt[i] - '0' : -1;
+                    const int bt = bgt && (int)strlen(bgt) > i ? (bgt[i] >= '0' && bgt[i] <= '9' ? bgt[i] - '0' : (bgt[i] >= 'a' && bgt[i] <= 'f' ? bgt[i] - 'a' + 10 : -1)) : -1;
                     conv_bf3_group(G1, stream, bt);
                     conv_bf3_group(G2, stream, bt);
                     mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;

@@ -149,6 +149,7 @@ struct ResLayerArgs {
     const float *w1, *b1, *w2, *b2;           // packed [k][C][C] (cout contiguous), biases may be null
     int k1, dil1, k2;
     const float *wu1, *wu2;                   // Winograd-domain copies [seg][4][C][C] (wino_pack) or null
+    const void *wb1, *wb2;                    // split-bf16 copies (bf3_pack; wb2 with the k order of the parked intermediate) or null
 };
 struct ResLayerGroup {
     ResLayerArgs g[kMaxGroup];                // must stay the first member (indexed through the kernarg pointer)
@@ -169,7 +170,12 @@ bool conv_bf3_group_eligible(const ConvGroup& G);
 void conv_bf3_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 // wp: packed fp32 weights [nslab][Cin_pad][Cout_pad] (nslab = taps, or phases x taps of a polyphase transposed conv)
 // -> dst: [slab-major, see conv_bf3.hip] 3 x bf16; returns the number of bytes written (dst == null: size query)
-size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst);
+// perm_k: the 16 input channels of a chunk in the order the fused layer kernel parks its intermediate in (k slot (h, e) of a
+// chunk = channel 8 (e >> 2) + 4 h + (e & 3): the accumulator rows one lane holds)
+size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst, bool perm_k = false);
+// one ResBlock1 layer on the bf16 matrix cores: x + conv2(lrelu(conv1_dilated(lrelu(x)))), whole input window staged once
+bool resblock_bf3_eligible(const ResLayerGroup& G);
+void resblock_bf3(const ResLayerGroup& G, hipStream_t st, int variant = -1);
 void conv_mfma_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 void conv_generic(const ConvArgs& a, hipStream_t st);
 

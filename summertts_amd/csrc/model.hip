@@ -135,16 +135,17 @@ bool pack_wino(Store& st, const HConv& h, DConv& d) {
 }
 
 // split-bf16 copy of an already packed conv (kernels.hpp: bf3_pack) for the bf16-matrix-core kernels of conv_bf3.hip
-bool pack_bf3(Store& st, DConv& d) {
+bool pack_bf3(Store& st, DConv& d, bool perm_k = false) {
     if (d.depthwise || d.Cin != d.Cin_pad || d.Cin < 32 || !d.w) return true;
+    if (perm_k && (d.transposed || d.Cin != d.Cout || d.Cout != d.Cout_pad || d.Cin > 64)) return true;
     const int nphase = d.transposed ? d.stride : 1, ntap = d.transposed ? d.J : d.k;
     const size_t bytes = bf3_pack(nullptr, nphase, ntap, d.Cin_pad, d.Cout_pad, nullptr);
     const float* dptr = nullptr;
     float* p = st.alloc((bytes + 3) / 4 + 1024, &dptr);     // + slack: unconditional prefetches run one step past the end
     if (!p) return false;
     const float* wh = st.host.data() + (d.w - st.dev);
-    bf3_pack(wh, nphase, ntap, d.Cin_pad, d.Cout_pad, p);
-    d.wb3 = dptr;
+    bf3_pack(wh, nphase, ntap, d.Cin_pad, d.Cout_pad, p, perm_k);
+    if (perm_k) d.wb3p = dptr; else d.wb3 = dptr;
     return true;
 }
 
@@ -361,7 +362,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         if (!r.ok || n <= 0 || n > 32) FAIL("resblock");
         rb.c1.resize(n); rb.c2.resize(n);
         for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i]) || !pack_wino(st, h, rb.c1[i]) || !pack_bf3(st, rb.c1[i])) FAIL("resblock convs1"); }
-        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i]) || !pack_bf3(st, rb.c2[i])) FAIL("resblock convs2"); }
+        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i]) || !pack_bf3(st, rb.c2[i]) || !pack_bf3(st, rb.c2[i], true)) FAIL("resblock convs2"); }
     }
     { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_post)) FAIL("conv_post"); }
     if (m.dec_type == 0 && m.is_ms == 1) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.dec_cond)) FAIL("decoder cond"); }

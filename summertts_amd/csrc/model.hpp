@@ -34,6 +34,7 @@ struct DConv {
     const float* bias_rows = nullptr;   // bias in source row order next to wc (== bias where the conv's rows are not permuted)
     const float* wu = nullptr;      // Winograd-domain copy [seg][4][Cin_pad][Cout_pad] (narrow decoder ResBlock convs)
     const void* wb3 = nullptr;      // split-bf16 copy (conv_bf3.hip: three bf16 planes, fragment order) of the decoder trunk convs
+    const void* wb3p = nullptr;     // the same with the k order of resblock_bf3_kernel's parked intermediate (second conv of a narrow ResBlock layer)
     double macs_per_out = 0;   // true-tap MACs per output position (all output channels)
 };
 struct DLn { int C = 0; const float* g = nullptr; const float* b = nullptr; };
