@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak (~2.5 PF; 2495 measured)
+BF16_PRODUCTS_PER_F32 = 6       # conv_bf3.hip: six bf16 products per fp32 product (operands split into three bf16 terms)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -181,6 +183,10 @@ def main():
     ap.add_argument("--cpu-sample-phonemes", type=int, default=0, help="0 = the GPU step's utterance (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=0)
+    ap.add_argument("--conv-math", default=os.environ.get("STS_CONV_MATH", "bf16x3"), choices=["bf16x3", "f32"],
+                    help="arithmetic of the decoder trunk convs: bf16x3 = fp32 operands split exactly into three bf16 terms, six bf16 "
+                         "MFMA products per fp32 product, fp32 accumulation (default, same parity tolerances); f32 = the exact-fp32 MFMA")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed leg on the exact-fp32 MFMA path")
     ap.add_argument("--pipeline-engines", type=int, default=2,
                     help="extra (not the headline): throughput with this many engines fed by concurrent host threads, "
                          "so one utterance's latency-bound text side overlaps another's decoder; 0 disables")
@@ -225,6 +231,8 @@ def main():
     blob = sb.make_blob(cfg, 1234)
     syn = eng.Synthesizer(blob, device=dev_index)
     syn.set_conv_mode(args.conv_mode)
+    if hasattr(syn, "set_conv_math"):
+        syn.set_conv_math(args.conv_math)
     if dist is not None and args.backend == "nccl" and hasattr(syn, "set_host_pcm"):
         syn.set_host_pcm(False)          # the PCM goes device-to-device into the RCCL gather
 
@@ -323,6 +331,35 @@ def main():
     elapsed = time.perf_counter() - t0
     last = syn.profile()
 
+    # ---- second timed leg (rank 0, one GPU): the same step with the trunk convs on the exact-fp32 MFMA instruction, so that
+    # the line carries both arithmetic paths measured in the same process
+    f32_leg = None
+    if dist is None and not stub and args.conv_math == "bf16x3" and not args.no_f32_leg and hasattr(syn, "set_conv_math"):
+        syn.set_conv_math("f32")
+        for _ in range(2):
+            step()
+        n2 = max(5, args.steps // 2)
+        acc2, samples2 = {}, 0
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            n, _pcm = step()
+            samples2 += n
+            for k, v in syn.profile().items():
+                acc2[k] = acc2.get(k, 0.0) + float(v)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t2
+        m2 = acc2.get("ms_decoder_mfma", 0.0)
+        a2 = (acc2.get("flops_decoder_mfma", 0.0) / (m2 * 1e-3)) / 1e12 if m2 > 0 else 0.0
+        i2 = (acc2.get("flops_decoder_mfma_executed", 0.0) / (m2 * 1e-3)) / 1e12 if m2 > 0 else 0.0
+        f32_leg = {"value": samples2 / e2, "unit": "samples/s", "x_realtime_16khz": samples2 / e2 / 16000.0, "steps": n2,
+                   "ms_per_step": 1e3 * e2 / n2, "dtype": "f32 (v_mfma_f32_32x32x2_f32, Winograd-domain fused layers)",
+                   "stage_ms_per_step": {k[3:]: acc2.get(k, 0.0) / n2 for k in ("ms_text_encoder", "ms_duration", "ms_flow", "ms_decoder")},
+                   "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": a2 / PEAK_F32_MFMA_TFLOPS, "mfma_issued_tflops": i2,
+                                "mfma_issued_frac": i2 / PEAK_F32_MFMA_TFLOPS}}
+        syn.set_conv_math("bf16x3")
+
     # ---- extra figure (not the headline): the native request pool (sts_pool: N engines, one worker thread each,
     # one FIFO).  "pipelined" = batch-1 requests only overlapped across engines (max_batch 1); "burst" = the same
     # requests submitted at once with dynamic packed batching (max_batch 8).
@@ -381,6 +418,9 @@ def main():
         mfma_ms, launches = acc.get("ms_decoder_mfma", 0.0), acc.get("decoder_mfma_launches", 0.0)
         achieved_tf = (acc.get("flops_decoder_mfma", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
         issued_tf = (acc.get("flops_decoder_mfma_executed", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        bf16_tf = (acc.get("flops_decoder_bf16_issued", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        split = bf16_tf > 0.0                       # the trunk ran on split operands (conv_bf3.hip)
+        peak_tf = PEAK_BF16_MFMA_TFLOPS / BF16_PRODUCTS_PER_F32 if split else PEAK_F32_MFMA_TFLOPS
         # per-stage rooflines of the part of the step that is NOT the matrix-core decoder: bound = max(bytes / HBM peak, flops / MFMA peak)
         stages = {}
         for name, kms, kfl, kby in (("text_encoder", "ms_text_encoder", "flops_text_encoder", "bytes_text_encoder"),
@@ -391,7 +431,7 @@ def main():
             fl = acc.get(kfl, 0.0) / steps
             by = acc.get(kby, 0.0) / steps
             t_hbm = by / (PEAK_HBM_GBS * 1e9) * 1e3
-            t_mfma = fl / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3
+            t_mfma = fl / ((peak_tf if name == "decoder" else PEAK_F32_MFMA_TFLOPS) * 1e12) * 1e3
             bound_ms = max(t_hbm, t_mfma)
             stages[name] = {"ms": ms, "gflop": fl / 1e9, "mbytes": by / 1e6, "bound": "hbm" if t_hbm >= t_mfma else "mfma",
                             "bound_ms": bound_ms, "frac_of_bound": (bound_ms / ms) if ms > 0 else None,
@@ -411,7 +451,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32 (decoder trunk convs: fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, "
+                      "f32 accumulation; everything else f32)") if split else "f32",
             "data": "synthetic (seeded random weights in the reference .bin grammar; ids[i]=(i*37+11) mod vocab); the reference's "
                     "real .bin models are absent from /root/reference, every number here is on synthetic weights",
             "config": {
@@ -422,24 +463,35 @@ def main():
                 "samples_per_step_rank0": int(last["samples"]), "parallelism": f"utterance-sharded x{world}",
                 "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("STS_BENCH_SELF_LAUNCHED") else
                                ("torchrun / external launcher" if world > 1 else "single process"),
-                "kernel_build_id": build_id,
+                "kernel_build_id": build_id, "conv_math": args.conv_math,
             },
             "stage_ms_per_step": {k: stages[k]["ms"] for k in ("text_encoder", "duration", "flow", "decoder")},
             "host_sync_wait_ms_per_step": acc.get("ms_sync_wait_host", 0.0) / steps,
             "roofline": {
-                "kernel": "conv_mfma_kernel + conv_mfma_group_kernel + resblock_wino_kernel / resblock_layer_kernel (decoder upsamplers + grouped / fused ResBlock convs, v_mfma_f32_32x32x2_f32)",
+                "kernel": ("conv_bf3_kernel + conv_bf3_group_kernel + resblock_bf3_kernel (decoder upsamplers + grouped / fused ResBlock convs, "
+                           "v_mfma_f32_32x32x16_bf16 on split operands)") if split else
+                          ("conv_mfma_kernel + conv_mfma_group_kernel + resblock_wino_kernel / resblock_layer_kernel (decoder upsamplers + "
+                           "grouped / fused ResBlock convs, v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma",
                 "achieved": achieved_tf,
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": peak_tf,
                 "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
+                "frac": achieved_tf / peak_tf,
+                "peak_definition": (f"bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF/s / {BF16_PRODUCTS_PER_F32} bf16 products per fp32 product "
+                                    "(MI355X_MICROARCH.md; the exact-fp32 MFMA peak is 157.3)") if split else
+                                   "v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)",
                 "traffic": traffic,
-                "achieved_definition": "ALGORITHMIC (direct-form, true-tap) FLOPs of the launches / their HIP-event time: the task's "
-                                       "roofline figure (SURVEY.md 8d).  It is an effective rate, not pipe utilisation -- see mfma_issued_*",
+                "achieved_definition": "ALGORITHMIC (direct-form, true-tap) fp32 FLOPs of the launches / their HIP-event time: the task's "
+                                       "roofline figure (SURVEY.md 8d).  It is an effective rate, not pipe utilisation -- see *_issued_*",
+                "bf16_issued_tflops": bf16_tf,
+                "bf16_issued_frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
+                "bf16_issued_definition": "bf16 matrix-core FLOPs the split-operand launches issue (6 x their algorithmic FLOPs) / the same "
+                                          "time, against the bf16 dense peak: <= 1 by construction",
                 "mfma_issued_tflops": issued_tf,
                 "mfma_issued_frac": issued_tf / PEAK_F32_MFMA_TFLOPS,
-                "mfma_issued_definition": "matrix-core FLOPs the launches execute (the Winograd-domain layer kernels need (4 n3 + 3 n2) / (2 k) "
-                                          "of a k-tap conv's products) / the same time: <= 1 by construction",
+                "mfma_issued_definition": "exact-fp32 matrix-core FLOPs executed by launches on the fp32 MFMA path (0 when the whole trunk runs "
+                                          "on split operands; with --conv-math f32 the Winograd-domain layer kernels need (4 n3 + 3 n2) / (2 k) of "
+                                          "a k-tap conv's products)",
                 "algorithmic_bytes_per_launch": acc.get("bytes_decoder_min", 0.0) / max(1.0, launches),
                 "launches_per_step": launches / steps,
                 "avg_launch_us": 1e3 * mfma_ms / max(1.0, launches),
@@ -457,6 +509,8 @@ def main():
                                 "gathered_samples_rank0": gathered[0],
                                 "note": "the gather of step k runs on a helper thread under step k + 1; gather_drain_wait is what was "
                                         "left un-overlapped when the clock stopped"}
+        if f32_leg is not None:
+            out["f32_mfma_leg"] = f32_leg
         if pipelined is not None:
             out["request_pool"] = pipelined
         if world == 1 and not args.no_cpu_baseline and not stub:

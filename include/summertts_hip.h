@@ -107,6 +107,12 @@ int sts_get_durations(sts_engine* e, int32_t* dur, int64_t capacity);
 /*   conv dispatch: 0 = automatic, 1 = force the generic VALU kernel everywhere, 2..7 = force LDS-staged
  *   matrix-core tile (idx-2), 8 / 9 = force the split-K matrix-core kernel (32 / 64 columns per workgroup) */
 int sts_set_conv_mode(sts_engine* e, int mode);
+/*   arithmetic of the decoder trunk's matrix-core convs (upsamplers + ResBlock convs, ~95 % of the FLOPs):
+ *   0 = fp32 operands split exactly into three bf16 terms each, six bf16 MFMA products per fp32 product, fp32 accumulation
+ *       (conv_bf3.hip; as accurate as 1 against float64, 6/16 of its matrix-pipe time) -- the default;
+ *   1 = the exact-fp32 MFMA instruction (v_mfma_f32_32x32x2_f32) everywhere.
+ *   The default can also be chosen with the environment variable STS_CONV_MATH = bf16x3 | f32. */
+int sts_set_conv_math(sts_engine* e, int mode);
 
 /* Per-stage device timing of the last run, measured with HIP events on the engine's own stream. */
 typedef struct sts_profile {
@@ -121,6 +127,8 @@ typedef struct sts_profile {
                                              kernels need (4 n3 + 3 n2) / (2 k) of a k-tap conv's direct-form products */
     double bytes_text_encoder, bytes_duration, bytes_flow;   /* algorithmic HBM bytes per stage (as bytes_decoder_min) */
     float ms_sync_wait_host;        /* host time blocked on the frame-count download (the one data-dependent sync) */
+    double flops_decoder_bf16_issued;     /* bf16 matrix-core FLOPs issued by the timed launches that run on split operands
+                                             (6 x their algorithmic FLOPs); 0 with sts_set_conv_math(1) */
 } sts_profile;
 int sts_set_profiling(sts_engine* e, int enable);
 int sts_get_profile(const sts_engine* e, sts_profile* p);

@@ -138,6 +138,12 @@ int sts_set_forced_durations(sts_engine* e, const int32_t* dur, int64_t count) {
 }
 
 int sts_set_record_taps(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.record_taps = enable != 0; return STS_OK; }
+int sts_set_conv_math(sts_engine* e, int mode) {
+    if (!e) return set_err(STS_EINVAL, "null engine");
+    if (mode != 0 && mode != 1) return set_err(STS_EINVAL, "conv math: 0 = split-bf16, 1 = exact fp32");
+    e->eng.conv_math = mode;
+    return STS_OK;
+}
 int sts_set_conv_mode(sts_engine* e, int mode) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.conv_mode = mode; return STS_OK; }
 int sts_set_host_pcm(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.host_pcm = enable != 0; return STS_OK; }
 int sts_set_profiling(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.profiling = enable != 0; return STS_OK; }

@@ -34,6 +34,9 @@ namespace sts {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef STS_EXP
+#define STS_EXP 0   // timing experiments only (tools/exp_build.sh); 0 in every shipped build
+#endif
 #ifndef STS_BF3_RA
 #define STS_BF3_RA 2     // A-fragment ring depth (prefetch distance RA - 1 steps)
 #endif
@@ -250,7 +253,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         lds_w[i] = sub * SUB + col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
     }
     float xr[SPW][8];
+    int as = 0;        // next A step to request
     auto load_x = [&](int c) {
+        if ((STS_EXP & 1) && c > 0) return;
         // one descriptor per 16-channel sub-chunk, based at its first row: rows ride in the scalar offset, the per-lane
         // offset (row half + position) is range-checked by the hardware
 #pragma unroll
@@ -263,6 +268,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             }
     };
     auto store_tile = [&](int bufi) {
+        if ((STS_EXP & 8) && bufi >= 0 && as > 2) return;
         unsigned char* sb = smem3 + bufi * BUF;
 #pragma unroll
         for (int i = 0; i < SPW; i++)
@@ -281,18 +287,19 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     // ---- main loop over steps (chunk, sub-chunk, tap): A fragments RA - 1 steps ahead (L2), B fragments one step ahead (LDS)
     constexpr int UNR = (RA % 2 == 0) ? RA : 2 * RA;
     u32x4 fa[RA][MW][3], fb[2][NW][3];
-    int sj = 0, ssub = 0, sc = 0, as = 0;
+    int sj = 0, ssub = 0, sc = 0;
     auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
         int nj = sj + 1, nsub = ssub, nc = sc;
         if (nj == a.ntap) { nj = 0; nsub = ssub + 1; if (nsub == NSUB) { nsub = 0; nc = sc + 1; } }
-        load_a(as++, anew);               // unconditional: past the last step it reads 0 beyond the descriptor, never used
+        if (!(STS_EXP & 2) || s < 2) load_a(as++, anew);               // unconditional: past the last step it reads 0 beyond the descriptor, never used
         if (nc != sc && s + 1 < nsteps) {
             store_tile(nc & 1);           // chunk nc's tile (in registers since the start of chunk sc)
-            __syncthreads();              // tile nc visible; everyone is done reading the buffer it replaces
+            if (!(STS_EXP & 4)) __syncthreads();              // tile nc visible; everyone is done reading the buffer it replaces
             if (nc + 1 < nchunk) load_x(nc + 1);
         }
-        load_b(nc & 1, nsub, nj, bnxt);   // past the last step: stale LDS inside the tile, never used
+        if (!(STS_EXP & 16) || s < 2) load_b(nc & 1, nsub, nj, bnxt);   // past the last step: stale LDS inside the tile, never used
         __builtin_amdgcn_sched_barrier(0);
+        if (!(STS_EXP & 64))
 #pragma unroll
         for (int p = 0; p < 6; p++)
 #pragma unroll
@@ -313,6 +320,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             if (s + u < nsteps) do_step(fa[u % RA], fa[(u + RA - 1) % RA], fb[u % 2], fb[(u + 1) % 2], s + u);
         });
 
+    if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
     bf3_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
 }
 
@@ -794,15 +802,18 @@ bool conv_bf3_eligible(const ConvArgs& a) {
     return true;
 }
 
+// Tile choice (tools/bench_variants.sh sweeps on MI355X): all rows of a <= 128-row block in one workgroup
+// (the staged window is split once) when that still yields >= 2 workgroups per CU; a grid-starved launch (the
+// 256-channel stage of one utterance: 252 such tiles) takes 32-row x 256-column tiles instead (4x the workgroups,
+// 3 waves per SIMD).
 static int pick_bf3_tile(int Cout_pad, long max_n, long units) {
     // units = utterances x group members x phases
-    if (Cout_pad % 64 != 0) return 4;
     if (Cout_pad % 128 == 0) {
         const long n128 = (max_n + 127) / 128 * (Cout_pad / 128) * units;
-        if (n128 >= 1024) return 0;
+        return n128 >= 512 ? 0 : 4;
     }
-    const long n64 = (max_n + 127) / 128 * (Cout_pad / 64) * units;
-    return n64 >= 512 ? 3 : 3;
+    if (Cout_pad % 64 == 0) return 3;
+    return 4;
 }
 
 template <int MW, int NW, int WM, int WN, int NSUB>

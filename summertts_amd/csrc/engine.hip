@@ -38,7 +38,10 @@ Engine::~Engine() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+static int default_conv_math();
+
 int Engine::init(const float* blob, int64_t bytes, int dev) {
+    conv_math = default_conv_math();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(STS_EDEVICE, "no HIP device visible: the SummerTTS HIP engine needs an AMD GPU (gfx950) -- there is no CPU fallback");
@@ -91,8 +94,11 @@ void Engine::stage_begin(int s) { cur_stage_ = s; }
 void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); }
 
 // builds the kernel arguments of one conv and books its FLOPs / minimum HBM bytes
-// STS_BF3=1: decoder trunk convs on the bf16 matrix cores (split operands, conv_bf3.hip)
-static bool bf3_on() { static const bool on = getenv("STS_BF3") != nullptr && atoi(getenv("STS_BF3")) != 0; return on; }
+// default arithmetic of the trunk convs: STS_CONV_MATH = bf16x3 (split operands on the bf16 matrix cores, conv_bf3.hip) | f32
+static int default_conv_math() {
+    const char* v = getenv("STS_CONV_MATH");
+    return v && (!strcmp(v, "f32") || !strcmp(v, "fp32") || !strcmp(v, "1")) ? 1 : 0;
+}
 
 ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o, double* flops) {
     ConvArgs a;
@@ -132,8 +138,8 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     double fl = 0;
     const ConvArgs a = conv_args(c, x, lin, y, lout, o, &fl);
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
-    if (conv_mode == 0 && bf3_on() && in_mfma_region_ && o.tile < 0 && conv_bf3_eligible(a)) {
-        mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_++;
+    if (conv_mode == 0 && (conv_math == 0) && in_mfma_region_ && o.tile < 0 && conv_bf3_eligible(a)) {
+        mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_++;
         static const int bt = getenv("STS_BF3_TILE") ? atoi(getenv("STS_BF3_TILE")) : -1;   // experiment knob
         conv_bf3(a, cur_, bt);
     } else if (can_mfma) {
@@ -290,7 +296,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     memset(&prof, 0, sizeof(prof));
     for (double& f : flops_) f = 0;
     for (double& f : bytes_) f = 0;
-    mfma_flops_ = 0; mfma_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+    mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
 
     // ---------------- host-side batch geometry (phoneme level)
     std::vector<int> offT(B), lenT(B);
@@ -703,8 +709,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 static const int fuse_maxc = getenv("STS_FUSE_MAXC") ? atoi(getenv("STS_FUSE_MAXC")) : 128;   // experiment knob
                 bool fuse = !no_fuse && R.C <= fuse_maxc;
                 static const bool bf3_nofuse = getenv("STS_BF3_NOFUSE") != nullptr;   // experiment knob
-                const bool bf3_layer = bf3_on() && !bf3_nofuse;
-                if (bf3_on() && (R.C > 64 || bf3_nofuse)) fuse = false;
+                const bool bf3_layer = (conv_math == 0) && !bf3_nofuse;
+                if ((conv_math == 0) && (R.C > 64 || bf3_nofuse)) fuse = false;
                 for (int j = 0; j < nk && fuse; j++) {
                     const DResBlock& rb = M.rb[(size_t)i * nk + j];
                     const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
@@ -738,7 +744,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     if (bf3_layer && resblock_bf3_eligible(R)) {
                         static const int bv = getenv("STS_BF3_LAYER_VARIANT") ? atoi(getenv("STS_BF3_LAYER_VARIANT")) : -1;   // experiment knob
                         resblock_bf3(R, stream, bv);
-                        mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_ += 1;
+                        mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_ += 1;
                         continue;
                     }
                     if (per_chain) {
@@ -776,12 +782,12 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
                     continue;
                 }
-                if (bf3_on() && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
+                if ((conv_math == 0) && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
                     static const char* bgt = getenv("STS_BF3_GROUP_TILE");   // experiment knob: per-stage tile digits
                     const int bt = bgt && (int)strlen(bgt) > i ? (bgt[i] >= '0' && bgt[i] <= '9' ? bgt[i] - '0' : (bgt[i] >= 'a' && bgt[i] <= 'f' ? bgt[i] - 'a' + 10 : -1)) : -1;
                     conv_bf3_group(G1, stream, bt);
                     conv_bf3_group(G2, stream, bt);
-                    mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
+                    mfma_flops_ += fl1 + fl2; bf16_exec_ += 6.0 * (fl1 + fl2); mfma_launches_ += 2;
                     continue;
                 }
                 if (conv_group_eligible(G1)) conv_mfma_group(G1, stream, gtile);
@@ -912,7 +918,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     prof.frames = Ftot; prof.samples = Ntot; prof.phonemes = Ttot;
     prof.flops_text_encoder = flops_[0]; prof.flops_duration = flops_[1]; prof.flops_flow = flops_[2]; prof.flops_decoder = flops_[3];
     prof.flops_decoder_mfma = mfma_flops_; prof.decoder_mfma_launches = mfma_launches_; prof.bytes_decoder_min = bytes_[3] + 2.0 * (double)Ntot;
-    prof.flops_decoder_mfma_executed = mfma_exec_;
+    prof.flops_decoder_mfma_executed = mfma_exec_; prof.flops_decoder_bf16_issued = bf16_exec_;
     prof.bytes_text_encoder = bytes_[0]; prof.bytes_duration = bytes_[1]; prof.bytes_flow = bytes_[2];
     prof.ms_sync_wait_host = (float)sync_wait_ms_;
     if (profiling) {

@@ -69,6 +69,7 @@ public:
     std::vector<int32_t> forced_dur; bool have_forced = false;
     bool record_taps = false, profiling = false;
     int conv_mode = 0;
+    int conv_math = 0;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA (sts_set_conv_math)
     hipStream_t stream = nullptr;
 
 private:
@@ -100,7 +101,7 @@ private:
     int cur_stage_ = 0;
     double flops_[4] = {0, 0, 0, 0};
     double bytes_[4] = {0, 0, 0, 0};
-    double mfma_flops_ = 0, mfma_exec_ = 0, sync_wait_ms_ = 0; int mfma_launches_ = 0; bool in_mfma_region_ = false;
+    double mfma_flops_ = 0, mfma_exec_ = 0, bf16_exec_ = 0, sync_wait_ms_ = 0; int mfma_launches_ = 0; bool in_mfma_region_ = false;
 };
 
 }  // namespace sts

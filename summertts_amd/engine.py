@@ -38,7 +38,7 @@ class Profile(C.Structure):
                 ("flops_decoder_mfma", C.c_double), ("bytes_decoder_min", C.c_double), ("frames", C.c_int64),
                 ("samples", C.c_int64), ("phonemes", C.c_int64), ("flops_decoder_mfma_executed", C.c_double),
                 ("bytes_text_encoder", C.c_double), ("bytes_duration", C.c_double), ("bytes_flow", C.c_double),
-                ("ms_sync_wait_host", C.c_float)]
+                ("ms_sync_wait_host", C.c_float), ("flops_decoder_bf16_issued", C.c_double)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -70,6 +70,7 @@ def load_library() -> C.CDLL:
     lib.sts_set_forced_durations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.sts_set_record_taps.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_conv_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.sts_set_conv_math.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_host_pcm.argtypes = [C.c_void_p, C.c_int]
     lib.sts_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
@@ -88,7 +89,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "sts_create", "sts_destroy", "sts_speaker_num", "sts_get_info", "sts_infer_ids", "sts_infer_ids_batch",
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
-    "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_profiling",
+    "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_conv_math", "sts_set_profiling",
     "sts_get_profile", "sts_set_host_pcm", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
     "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
@@ -199,6 +200,12 @@ class Synthesizer:
 
     def set_record_taps(self, on: bool):
         _check(self.lib, self.lib.sts_set_record_taps(self.h, 1 if on else 0))
+
+    def set_conv_math(self, mode):
+        """Arithmetic of the decoder trunk convs: 0 / 'bf16x3' = fp32 operands as three bf16 terms on the bf16 matrix cores
+        (default), 1 / 'f32' = the exact-fp32 MFMA instruction."""
+        m = {"bf16x3": 0, "f32": 1}.get(mode, mode)
+        _check(self.lib, self.lib.sts_set_conv_math(self.h, int(m)))
 
     def set_conv_mode(self, mode: int):
         _check(self.lib, self.lib.sts_set_conv_mode(self.h, mode))
