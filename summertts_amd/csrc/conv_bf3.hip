@@ -806,8 +806,10 @@ bool conv_bf3_eligible(const ConvArgs& a) {
 // (the staged window is split once) when that still yields >= 2 workgroups per CU; a grid-starved launch (the
 // 256-channel stage of one utterance: 252 such tiles) takes 32-row x 256-column tiles instead (4x the workgroups,
 // 3 waves per SIMD).
-static int pick_bf3_tile(int Cout_pad, long max_n, long units) {
+static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed = false) {
     // units = utterances x group members x phases
+    // (a polyphase transposed conv stages the same window once per phase and row block: always the tallest tile)
+    if (transposed) return Cout_pad % 128 == 0 ? 0 : (Cout_pad % 64 == 0 ? 3 : 4);
     if (Cout_pad % 128 == 0) {
         const long n128 = (max_n + 127) / 128 * (Cout_pad / 128) * units;
         return n128 >= 512 ? 0 : 4;
@@ -859,7 +861,7 @@ static void launch_bf3ws_group(const ConvGroup& G, hipStream_t st) {
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     const int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
-    if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase);
+    if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
     switch (tile) {
         case 16: launch_bf3ws<2, 2, 2, 2, 2, 3>(a, nphase, st); break;
