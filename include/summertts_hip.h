@@ -110,7 +110,9 @@ int sts_set_conv_mode(sts_engine* e, int mode);
 /*   arithmetic of the decoder trunk's matrix-core convs (upsamplers + ResBlock convs, ~95 % of the FLOPs):
  *   0 = fp32 operands split exactly into three bf16 terms each, six bf16 MFMA products per fp32 product, fp32 accumulation
  *       (conv_bf3.hip; as accurate as 1 against float64, 6/16 of its matrix-pipe time) -- the default;
- *   1 = the exact-fp32 MFMA instruction (v_mfma_f32_32x32x2_f32) everywhere.
+ *   1 = the exact-fp32 MFMA instruction (v_mfma_f32_32x32x2_f32) everywhere;
+ *   2 = as 0, and also for every other eligible matrix-core conv (flow, text encoder) regardless of its grid size -- by default
+ *       those switch to the split form only from the batch size on at which they stop being launch-latency-bound (tests).
  *   The default can also be chosen with the environment variable STS_CONV_MATH = bf16x3 | f32. */
 int sts_set_conv_math(sts_engine* e, int mode);
 

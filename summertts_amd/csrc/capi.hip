@@ -140,7 +140,7 @@ int sts_set_forced_durations(sts_engine* e, const int32_t* dur, int64_t count) {
 int sts_set_record_taps(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.record_taps = enable != 0; return STS_OK; }
 int sts_set_conv_math(sts_engine* e, int mode) {
     if (!e) return set_err(STS_EINVAL, "null engine");
-    if (mode != 0 && mode != 1) return set_err(STS_EINVAL, "conv math: 0 = split-bf16, 1 = exact fp32");
+    if (mode < 0 || mode > 2) return set_err(STS_EINVAL, "conv math: 0 = split-bf16 (default), 1 = exact fp32, 2 = split-bf16 wherever eligible");
     e->eng.conv_math = mode;
     return STS_OK;
 }
@@ -229,7 +229,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         wino_pack(w, (long)k * Cin, Cin, 1, Cout, k, Cin, Cin_pad, Cout_pad, wu.data());
     }
     // modes 13 / 20..25 / 28..33: the split-bf16 kernel (conv_bf3.hip), automatic tile / tile code (mode - 20)
-    const bool bf3 = (mode == 13 || (mode >= 20 && mode < 40)) && !depthwise;
+    const bool bf3 = (mode == 13 || (mode >= 20 && mode < 41)) && !depthwise;
     std::vector<unsigned char> wb3;
     if (bf3) {
         wb3.resize(bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, nullptr));

@@ -167,11 +167,15 @@ __device__ __forceinline__ void bf3_epilogue(const ConvArgs& a, f32x16 (&acc)[MW
     });
 }
 
-template <int MW, int NW, int WM, int WN, int NSUB = 1, int RA = STS_BF3_RA>
+template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
     // NSUB: 16-channel sub-chunks staged per barrier (a staged chunk = 16 NSUB channels): fewer barriers and more bytes in
     // flight per workgroup for the few-tap convs, at NSUB x the staging registers and LDS
-    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NWAVE = WM * WN;
+    // KG: wave groups that split K inside the workgroup (a grid-starved conv with a long K loop: the 256-channel stage of one
+    // utterance has only 252 tiles of 128 x 128): group g owns the sub-chunks g, g + KG, ... of every staged chunk; the
+    // partial tiles are exchanged through LDS once, each group then finishes the column tiles q = g (mod KG)
+    static_assert(NSUB % KG == 0 && (KG == 1 || NW % KG == 0), "K groups take whole sub-chunks and whole column tiles");
+    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NTW = WM * WN, NWAVE = NTW * KG;
     constexpr int WIN = NT + MAX_HALO;                 // staged positions per chunk
     constexpr int NSLOT = WIN / 32;                    // staging slots of 32 positions x 16 channels (one wave-wide load group)
     constexpr int NITEM = NSLOT * NSUB;                // (sub-chunk, slot) items per staged chunk
@@ -188,7 +192,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int swave = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wave / WN, wn = wave % WN;
+    const int kg = swave / NTW;                                    // scalar
+    const int tw = wave - kg * NTW;
+    const int wm = tw / WN, wn = tw % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
     const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
@@ -206,15 +212,16 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int nchunk = a.Cin_pad / (CK * NSUB);
-    const int nsteps = nchunk * NSUB * a.ntap;
+    const int nsteps = nchunk * (NSUB / KG) * a.ntap;          // steps of ONE wave
+    const int nsteps_all = nchunk * NSUB * a.ntap;             // 16-channel x tap blocks of the packed weights
     const int nrt = a.Cout_pad / 32;
 
     // ---- A fragments: step s = (16-channel chunk) * ntap + tap is one contiguous block of nrt * 3 KB
-    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps * nrt * 3072));
+    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps_all * nrt * 3072));
     // (the wave's row tile goes into the per-lane offset: the compiler cannot prove tid >> 6 wave-uniform and would wrap
     // every load in a readfirstlane loop if it sat in the scalar offset)
     const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * 3072u;
-    const unsigned a_s0 = (unsigned)phase * (unsigned)nsteps * (unsigned)nrt * 3072u;
+    const unsigned a_s0 = (unsigned)phase * (unsigned)nsteps_all * (unsigned)nrt * 3072u;
     const unsigned a_step = (unsigned)nrt * 3072u;
     auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
         const unsigned sb = a_s0 + (unsigned)s * a_step;
@@ -284,14 +291,14 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             }
     };
 
-    // ---- main loop over steps (chunk, sub-chunk, tap): A fragments RA - 1 steps ahead (L2), B fragments one step ahead (LDS)
-    constexpr int UNR = (RA % 2 == 0) ? RA : 2 * RA;
-    u32x4 fa[RA][MW][3], fb[2][NW][3];
-    int sj = 0, ssub = 0, sc = 0;
+    // ---- main loop over this wave's steps (chunk, sub-chunk, tap): A (L2) and B (LDS) fragments one step ahead
+    u32x4 fa[2][MW][3], fb[2][NW][3];
+    int sj = 0, ssub = kg, sc = 0;
+    auto a_index = [&](int c, int sub, int j) { return (c * NSUB + sub) * a.ntap + j; };
     auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
         int nj = sj + 1, nsub = ssub, nc = sc;
-        if (nj == a.ntap) { nj = 0; nsub = ssub + 1; if (nsub == NSUB) { nsub = 0; nc = sc + 1; } }
-        if (!(STS_EXP & 2) || s < 2) load_a(as++, anew);               // unconditional: past the last step it reads 0 beyond the descriptor, never used
+        if (nj == a.ntap) { nj = 0; nsub = ssub + KG; if (nsub >= NSUB) { nsub = kg; nc = sc + 1; } }
+        if (!(STS_EXP & 2) || s < 2) load_a(a_index(nc, nsub, nj), anew);   // unconditional: past the last step it reads 0 beyond the descriptor, never used
         if (nc != sc && s + 1 < nsteps) {
             store_tile(nc & 1);           // chunk nc's tile (in registers since the start of chunk sc)
             if (!(STS_EXP & 4)) __syncthreads();              // tile nc visible; everyone is done reading the buffer it replaces
@@ -309,26 +316,63 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         sj = nj; ssub = nsub; sc = nc;
     };
     load_x(0);
-    static_for<0, RA - 1>([&](auto rc) { constexpr int r = decltype(rc)::value; load_a(as++, fa[r]); });
+    load_a(a_index(0, kg, 0), fa[0]);
     store_tile(0);
     __syncthreads();
-    load_b(0, 0, 0, fb[0]);
+    load_b(0, kg, 0, fb[0]);
     if (nchunk > 1) load_x(1);
-    for (int s = 0; s < nsteps; s += UNR)
-        static_for<0, UNR>([&](auto uc) {
+    for (int s = 0; s < nsteps; s += 2)
+        static_for<0, 2>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            if (s + u < nsteps) do_step(fa[u % RA], fa[(u + RA - 1) % RA], fb[u % 2], fb[(u + 1) % 2], s + u);
+            if (s + u < nsteps) do_step(fa[u % 2], fa[(u + 1) % 2], fb[u % 2], fb[(u + 1) % 2], s + u);
         });
 
+    if constexpr (KG > 1) {
+        // ---- exchange the partial tiles: group g gives away its sums for the column tiles it does not finish
+        constexpr int REG = NTW * MW * (NW / KG) * 16 * 64;        // floats per owner region
+        float* red = (float*)smem3;
+        __syncthreads();                                           // every wave is done with the staged tiles
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, NW>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int owner = q % KG;
+                if (kg != owner) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        red[(size_t)owner * REG + (((size_t)(tw * MW + i) * (NW / KG) + q / KG) * 16 + r) * 64 + lane] = acc[i][q][r];
+                }
+            });
+        });
+        __syncthreads();
+        static_for<0, KG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (kg == g) {
+                f32x16 mine[MW][NW / KG];
+                static_for<0, MW>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, NW / KG>([&](auto qc) {
+                        constexpr int qq = decltype(qc)::value;
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            mine[i][qq][r] = acc[i][qq * KG + g][r] + red[(size_t)g * REG + (((size_t)(tw * MW + i) * (NW / KG) + qq) * 16 + r) * 64 + lane];
+                    });
+                });
+                static_assert(KG == 1 || NW / KG == 1, "one column tile per group");
+                bf3_epilogue<MW, NW / KG>(a, mine, mbase, n0 + wn * NW * 32 + g * 32, l31, half, n_count, out_len, out_base, phase, b);
+            }
+        });
+        return;
+    }
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
     bf3_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
 }
 
-template <int MW, int NW, int WM, int WN, int NSUB>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny) {
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny) {
     const TileId t = map_tile(nx, ny, a.B);
     if (!t.valid) return;
-    conv_bf3_body<MW, NW, WM, WN, NSUB>(a, mtiles, t.bx, t.by, t.bz);
+    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(a, mtiles, t.bx, t.by, t.bz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,13 +543,13 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) __attribute__((amdgpu_waves_pe
 }
 
 // grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
-template <int MW, int NW, int WM, int WN, int NSUB>
-__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
     const TileId t = map_tile(nx, ny, B * G.n);
     if (!t.valid) return;
     const int gi = t.bz / B;
     const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_bf3_body<MW, NW, WM, WN, NSUB>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
+    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -788,7 +832,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
 constexpr int kNumBf3Tiles = 6;
-static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 16 && tile < 20); }
+static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 16 && tile < 21); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
     if (!a.wb3 || a.depthwise || a.in_reflect) return false;
@@ -809,7 +853,11 @@ bool conv_bf3_eligible(const ConvArgs& a) {
 static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed = false) {
     // units = utterances x group members x phases
     // (a polyphase transposed conv stages the same window once per phase and row block: always the tallest tile)
-    if (transposed) return Cout_pad % 128 == 0 ? 0 : (Cout_pad % 64 == 0 ? 3 : 4);
+    if (transposed) {
+        // (few tiles and a long K -- HiFi-GAN's first upsampler at one utterance: 6 x 2 x 8 tiles, K = 2 x 512 -- : K split over two wave groups)
+        if (Cout_pad % 128 == 0) return (max_n + 127) / 128 * (Cout_pad / 128) * units < 256 ? 20 : 0;
+        return Cout_pad % 64 == 0 ? 3 : 4;
+    }
     if (Cout_pad % 128 == 0) {
         const long n128 = (max_n + 127) / 128 * (Cout_pad / 128) * units;
         return n128 >= 512 ? 0 : 4;
@@ -818,25 +866,26 @@ static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed =
     return 4;
 }
 
-template <int MW, int NW, int WM, int WN, int NSUB>
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
 static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT, ny = mt * nphase;
     const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
-    hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * 64), lds, st, a, mt, nx, ny);
+    hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * KG * 64), lds, st, a, mt, nx, ny);
 }
-template <int MW, int NW, int WM, int WN, int NSUB>
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
 static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     const ConvArgs& a = G.g[0];
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT;
     const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
-    hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * 64), lds, st, G,
+    hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * KG * 64), lds, st, G,
                        mt, a.B, nx, mt);
 }
 
+// 20: 128 x 128 with K split over two wave groups inside the workgroup (8 waves, 32-channel staged chunks)
 // wave-specialised tiles: 16: 128 x 128 (4 consumer waves of 64 x 64 + 2 producers)   17: 64 x 128 (2 + 1)
 //                         18: 128 x 256 (8 + 2)                                        19: 64 x 256 (4 + 2)
 template <int MW, int NW, int WM, int WN, int NP, int D>
@@ -858,12 +907,20 @@ static void launch_bf3ws_group(const ConvGroup& G, hipStream_t st) {
                        mt, a.B, nx, mt);
 }
 
+long conv_bf3_blocks(const ConvArgs& a) {
+    const int nphase = a.transposed ? a.out_stride : 1;
+    const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
+    const int mt = tile == 4 ? 32 : (tile == 3 ? 64 : 128), nt = tile == 4 ? 256 : 128;
+    return (long)((a.max_n + nt - 1) / nt) * ((a.Cout_pad + mt - 1) / mt) * nphase * a.B;
+}
+
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     const int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
     if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
     switch (tile) {
+        case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
         case 16: launch_bf3ws<2, 2, 2, 2, 2, 3>(a, nphase, st); break;
         case 17: launch_bf3ws<2, 2, 1, 2, 1, 2>(a, nphase, st); break;
         case 18: launch_bf3ws<2, 2, 2, 4, 2, 3>(a, nphase, st); break;
@@ -905,6 +962,8 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
     if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n);
     if (tile >= 8 && tile < 16) for (int i = 0; i < G.n; i++) if (G.g[i].Cin_pad % 32 != 0) { tile -= 8; break; }
     switch (tile) {
+        case 20: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
+                   if (ok) launch_bf3_group<2, 2, 2, 2, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
         case 16: launch_bf3ws_group<2, 2, 2, 2, 2, 3>(G, st); break;
         case 17: launch_bf3ws_group<2, 2, 1, 2, 1, 2>(G, st); break;
         case 18: launch_bf3ws_group<2, 2, 2, 4, 2, 3>(G, st); break;

@@ -138,8 +138,11 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     double fl = 0;
     const ConvArgs a = conv_args(c, x, lin, y, lout, o, &fl);
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
-    if (conv_mode == 0 && (conv_math == 0) && in_mfma_region_ && o.tile < 0 && conv_bf3_eligible(a)) {
-        mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_++;
+    // split-bf16 arithmetic: the decoder trunk always; other matrix-core convs (flow, text encoder, conv_pre) from the grid size on
+    // at which they stop being launch-latency-bound (a batch of a few dozen utterances); conv_math 2 = wherever eligible (tests)
+    if (conv_mode == 0 && conv_math != 1 && o.tile < 0 && conv_bf3_eligible(a) &&
+        (in_mfma_region_ || conv_math == 2 || conv_bf3_blocks(a) >= 384)) {
+        if (in_mfma_region_) { mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_++; }
         static const int bt = getenv("STS_BF3_TILE") ? atoi(getenv("STS_BF3_TILE")) : -1;   // experiment knob
         conv_bf3(a, cur_, bt);
     } else if (can_mfma) {
@@ -709,8 +712,8 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 static const int fuse_maxc = getenv("STS_FUSE_MAXC") ? atoi(getenv("STS_FUSE_MAXC")) : 128;   // experiment knob
                 bool fuse = !no_fuse && R.C <= fuse_maxc;
                 static const bool bf3_nofuse = getenv("STS_BF3_NOFUSE") != nullptr;   // experiment knob
-                const bool bf3_layer = (conv_math == 0) && !bf3_nofuse;
-                if ((conv_math == 0) && (R.C > 64 || bf3_nofuse)) fuse = false;
+                const bool bf3_layer = (conv_math != 1) && !bf3_nofuse;
+                if ((conv_math != 1) && (R.C > 64 || bf3_nofuse)) fuse = false;
                 for (int j = 0; j < nk && fuse; j++) {
                     const DResBlock& rb = M.rb[(size_t)i * nk + j];
                     const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
@@ -782,9 +785,9 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
                     continue;
                 }
-                if ((conv_math == 0) && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
+                if ((conv_math != 1) && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
                     static const char* bgt = getenv("STS_BF3_GROUP_TILE");   // experiment knob: per-stage tile digits
-                    const int bt = bgt && (int)strlen(bgt) > i ? (bgt[i] >= '0' && bgt[i] <= '9' ? bgt[i] - '0' : (bgt[i] >= 'a' && bgt[i] <= 'f' ? bgt[i] - 'a' + 10 : -1)) : -1;
+                    const int bt = bgt && (int)strlen(bgt) > i ? (bgt[i] >= '0' && bgt[i] <= '9' ? bgt[i] - '0' : (bgt[i] >= 'a' && bgt[i] <= 'z' ? bgt[i] - 'a' + 10 : -1)) : -1;
                     conv_bf3_group(G1, stream, bt);
                     conv_bf3_group(G2, stream, bt);
                     mfma_flops_ += fl1 + fl2; bf16_exec_ += 6.0 * (fl1 + fl2); mfma_launches_ += 2;

@@ -166,6 +166,8 @@ bool conv_group_eligible(const ConvGroup& G);
 // bits), the six products of order <= 2^-16 accumulated in fp32 (conv_bf3.hip)
 bool conv_bf3_eligible(const ConvArgs& a);
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile = -1);
+// workgroups the automatic tile choice would launch (the caller keeps latency-bound launches on the split-K fp32 kernel)
+long conv_bf3_blocks(const ConvArgs& a);
 bool conv_bf3_group_eligible(const ConvGroup& G);
 void conv_bf3_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 // wp: packed fp32 weights [nslab][Cin_pad][Cout_pad] (nslab = taps, or phases x taps of a polyphase transposed conv)

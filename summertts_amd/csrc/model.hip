@@ -312,7 +312,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         }
         HConv cat; cat.out_ch = 3 * a.ch; cat.in_ch = a.ch; cat.k = 1; cat.pad = 0; cat.dil = 1; cat.has_bias = anyb ? 1 : 0;
         cat.w = wcat.data(); cat.b = bcat.data();
-        if (!pack_conv(st, cat, PackOpts(), a.qkv) || !pack_conv(st, o, PackOpts(), a.o) || !pack_col(st, o, a.o) || !pack_col(st, cat, a.qkv))
+        if (!pack_conv(st, cat, PackOpts(), a.qkv) || !pack_bf3(st, a.qkv) || !pack_conv(st, o, PackOpts(), a.o) || !pack_bf3(st, a.o) || !pack_col(st, o, a.o) || !pack_col(st, cat, a.qkv))
             FAIL("weight store overflow");
     }
     for (int i = 0; i < m.n_layers; i++) { HLn h = parse_ln(r); if (!r.ok || !pack_ln(st, h, m.ln1[i])) FAIL("ln1"); }
@@ -320,7 +320,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         m.ffn[i].ksize = r.geti();
         HConv c1 = parse_conv(r), c2 = parse_conv(r);
         if (!r.ok || c1.k != m.ffn[i].ksize || c2.k != m.ffn[i].ksize || c1.pad != 0 || c2.pad != 0) FAIL("ffn convs");
-        if (!pack_conv(st, c1, PackOpts(), m.ffn[i].c1) || !pack_conv(st, c2, PackOpts(), m.ffn[i].c2)) FAIL("ffn pack");
+        if (!pack_conv(st, c1, PackOpts(), m.ffn[i].c1) || !pack_bf3(st, m.ffn[i].c1) || !pack_conv(st, c2, PackOpts(), m.ffn[i].c2) || !pack_bf3(st, m.ffn[i].c2)) FAIL("ffn pack");
     }
     for (int i = 0; i < m.n_layers; i++) { HLn h = parse_ln(r); if (!r.ok || !pack_ln(st, h, m.ln2[i])) FAIL("ln2"); }
     {
@@ -344,7 +344,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
     if (!r.ok || m.n_resk <= 0 || m.n_resk > 32) FAIL("bad resblock kernel list");
     for (int i = 0; i < m.n_resk; i++) r.geti();
     { int nd = r.geti(); if (!r.ok || nd < 0 || nd > 64) FAIL("bad dilation table"); r.take(3 * (int64_t)nd); }
-    { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_pre)) FAIL("conv_pre"); }
+    { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_pre) || !pack_bf3(st, m.conv_pre)) FAIL("conv_pre"); }
     m.ups.resize(m.n_up);
     m.hop_total = 1;
     for (int i = 0; i < m.n_up; i++) {
@@ -394,7 +394,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         c.flipped = ((m.n_flows - i) & 1) != 0;
         HConv pre = parse_conv(r);
         if (!r.ok || pre.k != 1 || pre.in_ch != m.inter / 2) FAIL("coupling pre");
-        { PackOpts o; o.reverse_in = c.flipped; if (!pack_conv(st, pre, o, c.pre)) FAIL("coupling pre pack"); }
+        { PackOpts o; o.reverse_in = c.flipped; if (!pack_conv(st, pre, o, c.pre) || !pack_bf3(st, c.pre)) FAIL("coupling pre pack"); }
         DWn& w = c.wn;
         w.n = r.geti(); const int wk = r.geti();
         if (!r.ok || w.n <= 0 || w.n > 64) FAIL("WN header");
@@ -407,13 +407,13 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
             if (h.in_ch != w.H || h.out_ch != 2 * w.H || h.k != wk) FAIL("WN in_layer shape");
             h.pad = (wk * dil - dil) / 2; h.dil = dil;
             PackOpts o; o.gate = true; o.gate_H = w.H;
-            if (!pack_conv(st, h, o, w.in[l])) FAIL("WN in_layer pack");
+            if (!pack_conv(st, h, o, w.in[l]) || !pack_bf3(st, w.in[l])) FAIL("WN in_layer pack");
         }
         for (int l = 0; l < w.n; l++) {
             HConv h = parse_conv(r);
             if (!r.ok || h.k != 1 || h.in_ch != w.H || (h.out_ch != 2 * w.H && h.out_ch != w.H)) FAIL("WN res_skip");
             if ((l < w.n - 1) != (h.out_ch == 2 * w.H)) FAIL("WN res_skip shape");
-            if (!pack_conv(st, h, PackOpts(), w.rs[l])) FAIL("WN res_skip pack");
+            if (!pack_conv(st, h, PackOpts(), w.rs[l]) || !pack_bf3(st, w.rs[l])) FAIL("WN res_skip pack");
             w.rs[l].H = w.H;
         }
         w.has_cond = m.is_ms == 1;
@@ -425,7 +425,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         }
         HConv post = parse_conv(r);
         if (!r.ok || post.k != 1 || post.out_ch != m.inter / 2 || post.in_ch != w.H || pre.out_ch != w.H) FAIL("coupling post");
-        { PackOpts o; o.reverse_out = c.flipped; if (!pack_conv(st, post, o, c.post)) FAIL("coupling post pack"); }
+        { PackOpts o; o.reverse_out = c.flipped; if (!pack_conv(st, post, o, c.post) || !pack_bf3(st, c.post)) FAIL("coupling post pack"); }
     }
 
     // ---- duration predictor

@@ -204,7 +204,7 @@ class Synthesizer:
     def set_conv_math(self, mode):
         """Arithmetic of the decoder trunk convs: 0 / 'bf16x3' = fp32 operands as three bf16 terms on the bf16 matrix cores
         (default), 1 / 'f32' = the exact-fp32 MFMA instruction."""
-        m = {"bf16x3": 0, "f32": 1}.get(mode, mode)
+        m = {"bf16x3": 0, "f32": 1, "bf16x3_all": 2}.get(mode, mode)
         _check(self.lib, self.lib.sts_set_conv_math(self.h, int(m)))
 
     def set_conv_mode(self, mode: int):

@@ -92,18 +92,27 @@ def test_bf3_conv_is_as_accurate_as_the_fp32_matrix_core_kernel(case):
         assert err.max() <= 2e-5, (case, mode, err.max())
         assert np.sqrt(np.mean(err ** 2)) <= 1.5 * e32 + 1e-9, (case, mode, np.sqrt(np.mean(err ** 2)), e32)
         outs.append(y)
-    for y in outs[1:]:     # every tile shape walks K in the same order
-        assert np.array_equal(y, outs[0]), case
+    for y in outs[2:]:     # every explicit tile shape walks K in the same order (outs[0] = automatic choice: may split K)
+        assert np.array_equal(y, outs[1]), case
+    # K split over two wave groups of a workgroup (tile code 20): different summation order, same bounds
+    y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=40)
+    err = np.abs(y - ref)
+    assert err.max() <= 2e-5 and np.sqrt(np.mean(err ** 2)) <= 1.5 * e32 + 1e-9, (case, "kg2", err.max())
     # fused input leaky-relu is applied before the split
     y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=13)
     y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=13)
     assert np.array_equal(y, y1)
 
 
+CONV_MATHS = ["bf16x3", "f32", "bf16x3_all"]   # sts_set_conv_math 0 (default) / 1 / 2: same tolerances for all three
+
+
+@pytest.mark.parametrize("math", CONV_MATHS)
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1])
-def test_hip_matches_reference_golden(path):
+def test_hip_matches_reference_golden(path, math):
     g, cfg, blob = load_golden(path)
     syn = engine.Synthesizer(blob)
+    syn.set_conv_math(math)
     syn.set_record_taps(True)
     n = syn.run_batch([g["ids"]], [int(g["sid"])], [float(g["length_scale"])])
     dur = syn.durations(len(g["ids"]))
@@ -384,8 +393,9 @@ def test_realistic_size_against_the_real_reference():
     syn.close()
 
 
+@pytest.mark.parametrize("math", CONV_MATHS)
 @pytest.mark.parametrize("path", golden_files_v2("full_"), ids=lambda p: p.split("/")[-1])
-def test_full_size_configs_match_reference_golden(path):
+def test_full_size_configs_match_reference_golden(path, math):
     """BASELINE configs[2]-[4] at FULL model size against outputs of the real reference (tools/make_golden_full.py ran it):
     MB-iSTFT (PQMF) and MS-iSTFT decoders at 96 phonemes (the grouped / fused / Winograd kernels engage), the multi-speaker
     HiFi-GAN model (gin 256: cond paths of the duration predictor, the flow's WaveNet and the decoder) with three speaker
@@ -394,6 +404,7 @@ def test_full_size_configs_match_reference_golden(path):
     g, cfg, blob, utts, stride = load_golden_v2(path)
     syn = engine.Synthesizer(blob)
     assert syn.info.blob_floats_consumed == blob.size
+    syn.set_conv_math(math)     # split-bf16 trunk (default) / exact-fp32 MFMA / split-bf16 in every eligible conv: one tolerance
     syn.set_record_taps(True)
     if "batch_lens" in g:
         lens = [int(t) for t in g["batch_lens"]]
