@@ -27,6 +27,7 @@
 #include "devmath.hpp"
 #include "conv_common.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace sts {
@@ -544,12 +545,16 @@ __global__ __launch_bounds__((WM * WN + NP) * 64) __attribute__((amdgpu_waves_pe
 
 // grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny, int interleave) {
     const TileId t = map_tile(nx, ny, B * G.n);
     if (!t.valid) return;
-    const int gi = t.bz / B;
+    // interleave: consecutive dispatch units belong to different members (different K lengths), so that workgroups that
+    // share a CU do not run their load / MFMA / store phases in lockstep
+    int gi, bx, b;
+    if (interleave) { const int unit = t.bz * nx + t.bx; gi = unit % G.n; const int rest = unit / G.n; bx = rest % nx; b = rest / nx; }
+    else { gi = t.bz / B; bx = t.bx; b = t.bz - gi * B; }
     const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
+    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(ga[gi], mtiles, bx, t.by, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_e
 // 8 + 4 h + {0..3} of every 16-row block = one 16-byte unit per plane); conv2's weights are packed to match (perm_k).
 // ------------------------------------------------------------------------------------------------
 template <int MW, int WM, int NW, int WN>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_bf3_kernel(ResLayerGroup G, int nx, int wst) {
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_bf3_kernel(ResLayerGroup G, int nx, int wst, int interleave) {
     constexpr int C = 32 * MW * WM, NCH = C / 16, NRT = C / 32, NWAVE = WM * WN, P1 = 32 * NW * WN;
     constexpr int PLANE2 = P1 * 32, CHUNK2 = 3 * PLANE2;
     constexpr int MAXSLOT = (P1 + MAX_HALO) / 32;
@@ -572,13 +577,15 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const TileId t = map_tile(nx, 1, G.B * G.n);
     if (!t.valid) return;
-    const int gi = t.bz / G.B, b = t.bz - gi * G.B;
+    int gi, tbx, b;
+    if (interleave) { const int unit = t.bz * nx + t.bx; gi = unit % G.n; const int rest = unit / G.n; tbx = rest % nx; b = rest / nx; }
+    else { gi = t.bz / G.B; tbx = t.bx; b = t.bz - gi * G.B; }
     const ResLayerArgs& a = ((const ResLayerArgs*)__builtin_amdgcn_kernarg_segment_ptr())[gi];
     const int d = a.dil1;
     const int h1 = d * (a.k1 - 1) / 2, h2 = (a.k2 - 1) / 2;
     const int NT = P1 - 2 * h2;
     const int len = seg_len(G.seg, b);
-    const int n0 = t.bx * NT;
+    const int n0 = tbx * NT;
     if (n0 >= len) return;
     const size_t base = (size_t)seg_start(G.seg, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -881,8 +888,9 @@ static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT;
     const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
+    static const int il = getenv("STS_BF3_INTERLEAVE") ? atoi(getenv("STS_BF3_INTERLEAVE")) : 0;   // experiment knob
     hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * KG * 64), lds, st, G,
-                       mt, a.B, nx, mt);
+                       mt, a.B, nx, mt, il & 1);
 }
 
 // 20: 128 x 128 with K split over two wave groups inside the workgroup (8 waves, 32-channel staged chunks)
@@ -1009,7 +1017,8 @@ static void launch_resblock_bf3(const ResLayerGroup& G, hipStream_t st) {
     const int wst = (P1 + halo + 31) / 32 * 32;
     const size_t stage = (size_t)C * wst * 6, park = (size_t)C * P1 * 6 + 1024;    // + slack: conv2's taps of the discarded last columns
     const size_t lds = stage > park ? stage : park;
-    hipLaunchKernelGGL((resblock_bf3_kernel<MW, WM, NW, WN>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx, wst);
+    static const int il = getenv("STS_BF3_INTERLEAVE") ? atoi(getenv("STS_BF3_INTERLEAVE")) : 0;   // experiment knob
+    hipLaunchKernelGGL((resblock_bf3_kernel<MW, WM, NW, WN>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx, wst, (il >> 1) & 1);
 }
 
 // variant: -1 automatic; C = 64: 0 = (32 x 64 per wave, 2 x 2 waves), 1 = (64 x 64 per wave, 1 x 2 waves);

@@ -62,6 +62,8 @@ def test_conv_kernels_against_torch_fp32(case):
     assert np.array_equal(y, y1)
 
 
+CONV_MATHS = ["bf16x3", "f32", "bf16x3_all"]   # sts_set_conv_math 0 (default) / 1 / 2: same tolerances for all three
+
 BF3_CASES = [c for c in CONV_CASES if not c[7] and c[0] >= 32 and c[0] % 16 == 0 and c[1] >= 32] + [
     (512, 256, 16, 4, 1, 70, 8, False), (128, 96, 3, 1, 1, 4000, 0, False), (32, 32, 7, 9, 3, 5000, 0, False)]
 
@@ -104,7 +106,30 @@ def test_bf3_conv_is_as_accurate_as_the_fp32_matrix_core_kernel(case):
     assert np.array_equal(y, y1)
 
 
-CONV_MATHS = ["bf16x3", "f32", "bf16x3_all"]   # sts_set_conv_math 0 (default) / 1 / 2: same tolerances for all three
+def test_conv_math_setting_is_validated_and_reported():
+    """sts_set_conv_math: 0 / 1 / 2 accepted, anything else EINVAL; the profile reports bf16 matrix-core FLOPs only when the
+    trunk ran on split operands (6 x the algorithmic FLOPs), and none under the exact-fp32 setting."""
+    cfg = sb.full_cfg("mbb_fix")
+    blob = sb.make_blob(cfg, 99)
+    ids = sb.synthetic_ids(24, cfg.vocab)
+    syn = engine.Synthesizer(blob)
+    with pytest.raises(engine.StsError):
+        syn.set_conv_math(3)
+    with pytest.raises(engine.StsError):
+        syn.set_conv_math(-1)
+    syn.set_profiling(True)
+    pcm = {}
+    for math in CONV_MATHS:
+        syn.set_conv_math(math)
+        syn.run_batch([ids])
+        pcm[math] = syn.pcm_host().astype(np.int32).copy()
+        pr = syn.profile()
+        if math == "f32":
+            assert pr["flops_decoder_bf16_issued"] == 0.0
+        else:
+            assert pr["flops_decoder_mfma"] > 0 and abs(pr["flops_decoder_bf16_issued"] / pr["flops_decoder_mfma"] - 6.0) < 1e-6
+    assert np.abs(pcm["bf16x3"] - pcm["f32"]).max() <= 1 and np.abs(pcm["bf16x3_all"] - pcm["f32"]).max() <= 1
+    syn.close()
 
 
 @pytest.mark.parametrize("math", CONV_MATHS)
