@@ -38,9 +38,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef STS_EXP
 #define STS_EXP 0   // timing experiments only (tools/exp_build.sh); 0 in every shipped build
 #endif
-#ifndef STS_BF3_RA
-#define STS_BF3_RA 2     // A-fragment ring depth (prefetch distance RA - 1 steps)
-#endif
 
 // exact three-way split of 8 fp32 values (one lane's 8 channels) into bf16 planes; element e of a plane sits in the low
 // (e even) / high (e odd) half of dword e / 2 -- the order v_mfma_*_bf16 reads its 8 k values in
