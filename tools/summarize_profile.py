@@ -12,7 +12,7 @@
   profiles/latest_pmc.json          {"by_workload": {<key>: summary}} -- bench.py attaches a summary to its `roofline` object only
                                     when the workload key AND the kernel build id (sha256 of summertts_amd/csrc) match.
 
-Kernel classes are found by DISPATCH ORDER inside a step (a step starts at embed_kernel): the `--flow-launches` convs after
+Kernel classes are found by DISPATCH ORDER inside a step: the `--flow-launches` convs after a step's
 expand_frames_kernel are the reverse flow, the next launch is conv_pre, and everything up to the step's last sum_scale_kernel
 (sum_scale itself excluded) is the decoder trunk -- the upsamplers and the grouped / fused ResBlock layers, whichever kernel
 variant the dispatcher picked for them.
@@ -58,12 +58,11 @@ def short(name):
 def classify(names, flow_launches):
     """names: kernel names of ONE run in dispatch order -> list of labels ('flow', 'trunk', other)."""
     lab = ["other"] * len(names)
-    starts = [i for i, n in enumerate(names) if "embed_kernel" in n] + [len(names)]
+    # a step's acoustic half starts at its (single) expand_frames_kernel; the region runs to the next step's (the embedding
+    # kernel is not a usable marker: at batch it is fused into the first projection)
+    starts = [i for i, n in enumerate(names) if "expand_frames_kernel" in n] + [len(names)]
     for s, e in zip(starts[:-1], starts[1:]):
-        idx = [i for i in range(s, e) if "expand_frames_kernel" in names[i]]
-        if not idx:
-            continue
-        i = idx[0] + 1
+        i = s + 1
         nconv = 0
         while i < e and nconv < flow_launches:
             if "conv_" in names[i]:
@@ -113,7 +112,7 @@ def main():
     rows = sorted(csv.DictReader(open(newest(a.kt, "kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
     lab = classify(names, a.flow_launches)
-    nsteps = max(1, sum(1 for n in names if "embed_kernel" in n))
+    nsteps = max(1, sum(1 for n in names if "expand_frames_kernel" in n))
     summary = {"tag": a.tag, "workload": a.workload, "kernel_build_id": kernel_build_id(), "steps_in_trace": nsteps}
     for cls in ("trunk", "flow"):
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r, l in zip(rows, lab) if l == cls]
