@@ -989,7 +989,7 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
 }
 
 bool resblock_bf3_eligible(const ResLayerGroup& G) {
-    if (G.n < 1 || G.n > kMaxGroup || (G.C != 32 && G.C != 64) || G.max_n <= 0 || G.B <= 0) return false;
+    if (G.n < 1 || G.n > kMaxGroup || (G.C != 32 && G.C != 64 && G.C != 128) || G.max_n <= 0 || G.B <= 0) return false;
     if ((double)G.ld * 64.0 >= 4.0e9) return false;
     for (int i = 0; i < G.n; i++) {
         const ResLayerArgs& a = G.g[i];
@@ -1026,7 +1026,10 @@ void resblock_bf3(const ResLayerGroup& Gin, hipStream_t st, int variant) {
         for (int j = i; j > 0 && G.g[j].k1 + G.g[j].k2 > G.g[j - 1].k1 + G.g[j - 1].k2; j--) {
             ResLayerArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
         }
-    if (G.C == 64) {
+    if (G.C == 128) {
+        // the whole 128-channel window (147 KB of the CU's 160 KB LDS): one 8-wave workgroup per CU
+        if (variant == 1) launch_resblock_bf3<2, 2, 2, 2>(G, st); else launch_resblock_bf3<1, 4, 2, 2>(G, st);
+    } else if (G.C == 64) {
         if (variant == 1) launch_resblock_bf3<2, 1, 2, 2>(G, st); else launch_resblock_bf3<1, 2, 2, 2>(G, st);
     } else {
         if (variant == 1) launch_resblock_bf3<1, 1, 2, 2>(G, st); else launch_resblock_bf3<1, 1, 2, 4>(G, st);

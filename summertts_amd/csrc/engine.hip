@@ -713,7 +713,15 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 bool fuse = !no_fuse && R.C <= fuse_maxc;
                 static const bool bf3_nofuse = getenv("STS_BF3_NOFUSE") != nullptr;   // experiment knob
                 const bool bf3_layer = (conv_math != 1) && !bf3_nofuse;
-                if ((conv_math != 1) && (R.C > 64 || bf3_nofuse)) fuse = false;
+                // split-bf16 arithmetic: the 64/32-channel stages always run fused; the 128-channel stage (whole window = 147 KB of
+                // LDS, one 8-wave workgroup per CU) from ~8 tiles per CU on -- the trunk is power-bound at batch, so
+                // dropping the intermediate's HBM round trip pays (batch 8: -3 %), while a single utterance's 1 089 tiles on 256
+                // workgroup slots only tie the unfused pair
+                static const int bf3_fuse128_tiles = getenv("STS_BF3_FUSE128_TILES") ? atoi(getenv("STS_BF3_FUSE128_TILES")) : 2048;   // experiment knob
+                if (conv_math != 1) {
+                    if (bf3_nofuse || R.C > 128) fuse = false;
+                    else if (R.C > 64) fuse = fuse && (long)((l2.max_len + 117) / 118) * l2.nb * nk >= bf3_fuse128_tiles;
+                }
                 for (int j = 0; j < nk && fuse; j++) {
                     const DResBlock& rb = M.rb[(size_t)i * nk + j];
                     const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];

@@ -137,7 +137,7 @@ bool pack_wino(Store& st, const HConv& h, DConv& d) {
 // split-bf16 copy of an already packed conv (kernels.hpp: bf3_pack) for the bf16-matrix-core kernels of conv_bf3.hip
 bool pack_bf3(Store& st, DConv& d, bool perm_k = false) {
     if (d.depthwise || d.Cin != d.Cin_pad || d.Cin < 32 || !d.w) return true;
-    if (perm_k && (d.transposed || d.Cin != d.Cout || d.Cout != d.Cout_pad || d.Cin > 64)) return true;
+    if (perm_k && (d.transposed || d.Cin != d.Cout || d.Cout != d.Cout_pad || d.Cin > 128)) return true;
     const int nphase = d.transposed ? d.stride : 1, ntap = d.transposed ? d.J : d.k;
     const size_t bytes = bf3_pack(nullptr, nphase, ntap, d.Cin_pad, d.Cout_pad, nullptr);
     const float* dptr = nullptr;
