@@ -166,7 +166,9 @@ __device__ __forceinline__ void bf3_epilogue(const ConvArgs& a, f32x16 (&acc)[MW
 }
 
 template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1>
-__device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
+__device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b, const int pm = 0) {
+    // pm (polyphase transposed convs): the workgroup's MT rows run over the MERGED row space phase * Cout_pad + row, so that
+    // several phases (or all row blocks of a phase) share ONE staged, split input window instead of staging it once each
     // NSUB: 16-channel sub-chunks staged per barrier (a staged chunk = 16 NSUB channels): fewer barriers and more bytes in
     // flight per workgroup for the few-tap convs, at NSUB x the staging registers and LDS
     // KG: wave groups that split K inside the workgroup (a grid-starved conv with a long K loop: the 256-channel stage of one
@@ -185,8 +187,8 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     const int n_count = a.transposed ? in_len + a.n_extra : out_len;
     const int n0 = bx * NT;
     if (n0 >= n_count) return;
-    const int phase = by / mtiles;
-    const int m0 = (by - phase * mtiles) * MT;
+    const int phase0 = pm ? 0 : by / mtiles;
+    const int m0 = pm ? by * MT : (by - phase0 * mtiles) * MT;
     const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int swave = __builtin_amdgcn_readfirstlane(wave);
@@ -199,7 +201,14 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     const int lo = first < last ? first : last, hi = first < last ? last : first;
     const int W = NT + (hi - lo);
     const int win0 = n0 + lo;
-    const int mbase = m0 + wm * MW * 32;
+    int mbase = m0 + wm * MW * 32;
+    int phase = phase0;
+    bool wvalid = true;
+    if (pm) {                                   // this wave's rows in the merged space -> (phase, row inside the phase)
+        phase = mbase / a.Cout_pad;
+        mbase -= phase * a.Cout_pad;
+        wvalid = phase < a.out_stride;
+    }
 
     f32x16 acc[MW][NW];
 #pragma unroll
@@ -218,8 +227,8 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps_all * nrt * 3072));
     // (the wave's row tile goes into the per-lane offset: the compiler cannot prove tid >> 6 wave-uniform and would wrap
     // every load in a readfirstlane loop if it sat in the scalar offset)
-    const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * 3072u;
-    const unsigned a_s0 = (unsigned)phase * (unsigned)nsteps_all * (unsigned)nrt * 3072u;
+    const unsigned a_voff = wvalid ? (unsigned)lane * 16u + ((unsigned)phase * (unsigned)nsteps_all * (unsigned)nrt + (unsigned)(mbase >> 5)) * 3072u : kOOB;
+    const unsigned a_s0 = 0u;
     const unsigned a_step = (unsigned)nrt * 3072u;
     auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
         const unsigned sb = a_s0 + (unsigned)s * a_step;
@@ -328,6 +337,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     if constexpr (KG > 1) {
         // ---- exchange the partial tiles: group g gives away its sums for the column tiles it does not finish
         constexpr int REG = NTW * MW * (NW / KG) * 16 * 64;        // floats per owner region
+        static_assert((size_t)KG * REG * 4 <= (size_t)2 * BUF, "the exchange must fit the (dead) staging buffers");
         float* red = (float*)smem3;
         __syncthreads();                                           // every wave is done with the staged tiles
         static_for<0, MW>([&](auto ic) {
@@ -357,20 +367,20 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
                     });
                 });
                 static_assert(KG == 1 || NW / KG == 1, "one column tile per group");
-                bf3_epilogue<MW, NW / KG>(a, mine, mbase, n0 + wn * NW * 32 + g * 32, l31, half, n_count, out_len, out_base, phase, b);
+                if (wvalid) bf3_epilogue<MW, NW / KG>(a, mine, mbase, n0 + wn * NW * 32 + g * 32, l31, half, n_count, out_len, out_base, phase, b);
             }
         });
         return;
     }
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
-    bf3_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
+    if (wvalid) bf3_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
 }
 
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny) {
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
     const TileId t = map_tile(nx, ny, a.B);
     if (!t.valid) return;
-    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(a, mtiles, t.bx, t.by, t.bz);
+    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(a, mtiles, t.bx, t.by, t.bz, pm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -836,7 +846,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
 constexpr int kNumBf3Tiles = 6;
-static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 16 && tile < 21); }
+static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 16 && tile < 24); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
     if (!a.wb3 || a.depthwise || a.in_reflect) return false;
@@ -858,9 +868,11 @@ static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed =
     // units = utterances x group members x phases
     // (a polyphase transposed conv stages the same window once per phase and row block: always the tallest tile)
     if (transposed) {
-        // (few tiles and a long K -- HiFi-GAN's first upsampler at one utterance: 6 x 2 x 8 tiles, K = 2 x 512 -- : K split over two wave groups)
+        // (few tiles and a long K -- HiFi-GAN's first upsampler at one utterance: 6 x 2 x 8 tiles, K = 2 x 512 -- : K split over two
+        // wave groups; narrow outputs: the phases share one workgroup's staged window, tile codes 22 / 23; measured per shape in
+        // profiles/r02_bf3_conv_microbench.log)
         if (Cout_pad % 128 == 0) return (max_n + 127) / 128 * (Cout_pad / 128) * units < 256 ? 20 : 0;
-        return Cout_pad % 64 == 0 ? 3 : 4;
+        return Cout_pad % 64 == 0 ? 22 : 23;
     }
     if (Cout_pad % 128 == 0) {
         const long n128 = (max_n + 127) / 128 * (Cout_pad / 128) * units;
@@ -871,12 +883,13 @@ static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed =
 }
 
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
-static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st) {
+static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st, int pm = 0) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
-    const int mt = (a.Cout_pad + MT - 1) / MT;
-    const int nx = (a.max_n + NT - 1) / NT, ny = mt * nphase;
+    pm = pm && a.transposed && (MW == 1 || a.Cout_pad % (32 * MW) == 0);    // a wave's rows must lie inside one phase
+    const int mt = pm ? (a.Cout_pad * nphase + MT - 1) / MT : (a.Cout_pad + MT - 1) / MT;
+    const int nx = (a.max_n + NT - 1) / NT, ny = pm ? mt : mt * nphase;
     const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
-    hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * KG * 64), lds, st, a, mt, nx, ny);
+    hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * KG * 64), lds, st, a, mt, nx, ny, pm);
 }
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
 static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
@@ -926,6 +939,10 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
     switch (tile) {
         case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
+        // phase-merged rows (transposed convs): 21: 256 x 128 (8 waves)   22: 128 x 128   23: 64 x 128 as two 32-row waves x 2
+        case 21: launch_bf3<2, 2, 4, 2, 1>(a, nphase, st, 1); break;
+        case 22: launch_bf3<2, 2, 2, 2, 1>(a, nphase, st, 1); break;
+        case 23: launch_bf3<1, 2, 2, 2, 1>(a, nphase, st, 1); break;
         case 16: launch_bf3ws<2, 2, 2, 2, 2, 3>(a, nphase, st); break;
         case 17: launch_bf3ws<2, 2, 1, 2, 1, 2>(a, nphase, st); break;
         case 18: launch_bf3ws<2, 2, 2, 4, 2, 3>(a, nphase, st); break;
