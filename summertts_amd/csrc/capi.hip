@@ -229,7 +229,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         wino_pack(w, (long)k * Cin, Cin, 1, Cout, k, Cin, Cin_pad, Cout_pad, wu.data());
     }
     // modes 13 / 20..25 / 28..33: the split-bf16 kernel (conv_bf3.hip), automatic tile / tile code (mode - 20)
-    const bool bf3 = (mode == 13 || (mode >= 20 && mode < 44)) && !depthwise;
+    const bool bf3 = (mode == 13 || (mode >= 20 && mode < 45)) && !depthwise;
     std::vector<unsigned char> wb3;
     if (bf3) {
         wb3.resize(bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, nullptr));

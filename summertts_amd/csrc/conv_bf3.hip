@@ -337,7 +337,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     if constexpr (KG > 1) {
         // ---- exchange the partial tiles: group g gives away its sums for the column tiles it does not finish
         constexpr int REG = NTW * MW * (NW / KG) * 16 * 64;        // floats per owner region
-        static_assert((size_t)KG * REG * 4 <= (size_t)2 * BUF, "the exchange must fit the (dead) staging buffers");
+        // (the launcher sizes the LDS allocation for max(staging buffers, exchange): bf3_lds_bytes)
         float* red = (float*)smem3;
         __syncthreads();                                           // every wave is done with the staged tiles
         static_for<0, MW>([&](auto ic) {
@@ -846,7 +846,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
 constexpr int kNumBf3Tiles = 6;
-static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 16 && tile < 24); }
+static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 16 && tile < 25); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
     if (!a.wb3 || a.depthwise || a.in_reflect) return false;
@@ -882,13 +882,20 @@ static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed =
     return 4;
 }
 
+template <int MW, int NW, int WM, int WN, int NSUB, int KG>
+static constexpr size_t bf3_lds_bytes() {
+    constexpr size_t stage = (size_t)6 * NSUB * (32 * NW * WN + MAX_HALO) * 32;
+    constexpr size_t xchg = KG > 1 ? (size_t)KG * WM * WN * MW * (NW / KG) * 16 * 64 * 4 : 0;     // partial tiles of the K groups
+    return stage > xchg ? stage : xchg;
+}
+
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
 static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st, int pm = 0) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     pm = pm && a.transposed && (MW == 1 || a.Cout_pad % (32 * MW) == 0);    // a wave's rows must lie inside one phase
     const int mt = pm ? (a.Cout_pad * nphase + MT - 1) / MT : (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT, ny = pm ? mt : mt * nphase;
-    const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
+    const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG>();
     hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * KG * 64), lds, st, a, mt, nx, ny, pm);
 }
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
@@ -897,13 +904,14 @@ static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
     const ConvArgs& a = G.g[0];
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT;
-    const size_t lds = (size_t)6 * NSUB * (NT + MAX_HALO) * 32;
+    const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG>();
     static const int il = getenv("STS_BF3_INTERLEAVE") ? atoi(getenv("STS_BF3_INTERLEAVE")) : 0;   // experiment knob
     hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * KG * 64), lds, st, G,
                        mt, a.B, nx, mt, il & 1);
 }
 
 // 20: 128 x 128 with K split over two wave groups inside the workgroup (8 waves, 32-channel staged chunks)
+// 24: 256 x 64, K split over two wave groups (8 waves): all rows of a 256-channel conv behind ONE staged window
 // wave-specialised tiles: 16: 128 x 128 (4 consumer waves of 64 x 64 + 2 producers)   17: 64 x 128 (2 + 1)
 //                         18: 128 x 256 (8 + 2)                                        19: 64 x 256 (4 + 2)
 template <int MW, int NW, int WM, int WN, int NP, int D>
@@ -940,6 +948,7 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     switch (tile) {
         case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
         // phase-merged rows (transposed convs): 21: 256 x 128 (8 waves)   22: 128 x 128   23: 64 x 128 as two 32-row waves x 2
+        case 24: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 4, 1, 2, 2>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
         case 21: launch_bf3<2, 2, 4, 2, 1>(a, nphase, st, 1); break;
         case 22: launch_bf3<2, 2, 2, 2, 1>(a, nphase, st, 1); break;
         case 23: launch_bf3<1, 2, 2, 2, 1>(a, nphase, st, 1); break;
@@ -986,6 +995,8 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
     switch (tile) {
         case 20: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
                    if (ok) launch_bf3_group<2, 2, 2, 2, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
+        case 24: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
+                   if (ok) launch_bf3_group<2, 2, 4, 1, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
         case 16: launch_bf3ws_group<2, 2, 2, 2, 2, 3>(G, st); break;
         case 17: launch_bf3ws_group<2, 2, 1, 2, 1, 2>(G, st); break;
         case 18: launch_bf3ws_group<2, 2, 2, 4, 2, 3>(G, st); break;
