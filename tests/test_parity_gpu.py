@@ -132,6 +132,24 @@ def test_conv_math_setting_is_validated_and_reported():
     syn.close()
 
 
+def test_conv_math_default_follows_the_environment():
+    """STS_CONV_MATH=f32 in the environment makes the exact-fp32 MFMA path the default of a new engine (read at engine
+    construction, so checked in a child process)."""
+    import os, subprocess, sys
+    code = ("import numpy as np; from summertts_amd import engine, synth_blob as sb;"
+            "cfg = sb.full_cfg('mbb_fix'); syn = engine.Synthesizer(sb.make_blob(cfg, 7)); syn.set_profiling(True);"
+            "syn.run_batch([sb.synthetic_ids(16, cfg.vocab)]); p = syn.profile();"
+            "print('BF16', p['flops_decoder_bf16_issued'] > 0, 'F32', p['flops_decoder_mfma_executed'] > 0)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for val, expect in (("f32", "BF16 False F32 True"), ("bf16x3", "BF16 True F32 False"), (None, "BF16 True F32 False")):
+        env = dict(os.environ)
+        env.pop("STS_CONV_MATH", None)
+        if val:
+            env["STS_CONV_MATH"] = val
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert expect in out.stdout, (val, out.stdout[-300:], out.stderr[-300:])
+
+
 @pytest.mark.parametrize("math", CONV_MATHS)
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1])
 def test_hip_matches_reference_golden(path, math):
