@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak (~2.5 PF; 2495 measured)
 BF16_PRODUCTS_PER_F32 = 6       # conv_bf3.hip: six bf16 products per fp32 product (operands split into three bf16 terms)
+SUSTAINED_BF16_SPLIT_TFLOPS = 1712.0   # tools/ubench/mfma_bf16_peak.hip on MI355X (profiles/r02_mfma_bf16_peak_ubench.log): what a bare loop of
+                                       # the kernel's MFMA sequence sustains on the hi/mid/lo planes of random fp32 data (data-dependent DVFS)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -483,6 +485,10 @@ def main():
                 "traffic": traffic,
                 "achieved_definition": "ALGORITHMIC (direct-form, true-tap) fp32 FLOPs of the launches / their HIP-event time: the task's "
                                        "roofline figure (SURVEY.md 8d).  It is an effective rate, not pipe utilisation -- see *_issued_*",
+                "sustained_mfma_ceiling": {"tflops_fp32_equivalent": SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32,
+                                           "frac": achieved_tf / (SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32),
+                                           "source": "profiles/r02_mfma_bf16_peak_ubench.log: bare MFMA loop on split-fp32 operand "
+                                                     "statistics, 1712 bf16 TF/s of the nominal 2500 (power management)"} if split else None,
                 "bf16_issued_tflops": bf16_tf,
                 "bf16_issued_frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
                 "bf16_issued_definition": "bf16 matrix-core FLOPs the split-operand launches issue (6 x their algorithmic FLOPs) / the same "
