@@ -120,25 +120,74 @@ __device__ __forceinline__ void bf3_epilogue(const ConvArgs& a, f32x16 (&acc)[MW
         return;
     }
     if (a.epi == EPI_GATE) {
+        // rows r and r + 8 of a lane's 16 accumulator rows are tile rows (c, c + 16): the tanh and the sigmoid pre-activation of one
+        // channel (model.hip gate_perm_row); a row tile's 16 bias values are requested together
         static_for<0, MW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            static_for<0, NW>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                const int n = ncol0 + q * 32 + l31;
-                const int pos = n * a.out_stride + out_off;
-                if (mbase + i * 32 < a.Cout_pad && n < n_count && pos >= 0 && pos < out_len) {
-                    const size_t opos = out_base + (size_t)pos;
-                    static_for<0, 8>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float vt = acc[i][q][r], vs = acc[i][q][r + 8];
-                        if (a.bias) { vt += a.bias[rowp]; vs += a.bias[rowp + 16]; }
-                        if (a.ubias) { vt += a.ubias[(size_t)rowp * a.ubias_ld + b]; vs += a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b]; }
-                        const int ch = (rowp >> 5) * 16 + (rowp & 15);
-                        if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(vt) * sigmoid_ref(vs);
-                    });
+            if (mbase + i * 32 < a.Cout_pad) {
+                float bt[8], bs[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    bt[r] = a.bias ? a.bias[rowp] : 0.f;
+                    bs[r] = a.bias ? a.bias[rowp + 16] : 0.f;
+                    if (a.ubias) { bt[r] += a.ubias[(size_t)rowp * a.ubias_ld + b]; bs[r] += a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b]; }
                 }
-            });
+                static_for<0, NW>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const int n = ncol0 + q * 32 + l31;
+                    const int pos = n * a.out_stride + out_off;
+                    if (n < n_count && pos >= 0 && pos < out_len) {
+                        const size_t opos = out_base + (size_t)pos;
+#pragma unroll
+                        for (int r = 0; r < 8; r++) {
+                            const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const int ch = (rowp >> 5) * 16 + (rowp & 15);
+                            if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(acc[i][q][r] + bt[r]) * sigmoid_ref(acc[i][q][r + 8] + bs[r]);
+                        }
+                    }
+                });
+            }
+        });
+        return;
+    }
+    if (a.epi == EPI_RESSKIP || a.epi == EPI_SUB) {
+        // read-modify-write epilogues of the flow (WN res/skip split, coupling "x1 -= m"): a column tile's 16 old values are
+        // requested together, then updated and stored
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (mbase + i * 32 < a.Cout_pad) {
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    bv[r] = a.bias ? a.bias[rowp] : 0.f;
+                    if (a.ubias && rowp < a.Cout) bv[r] += a.ubias[(size_t)rowp * a.ubias_ld + b];
+                }
+                static_for<0, NW>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const int n = ncol0 + q * 32 + l31;
+                    const int pos = n * a.out_stride + out_off;
+                    if (n < n_count && pos >= 0 && pos < out_len) {
+                        const size_t opos = out_base + (size_t)pos;
+                        float* p[16]; float old[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            bool ld = true;
+                            if (a.epi == EPI_SUB || (a.Cout != a.H && rowp < a.H)) p[r] = a.y + (size_t)rowp * a.y_ld + opos;
+                            else { p[r] = a.aux + (size_t)(a.Cout != a.H ? rowp - a.H : rowp) * a.aux_ld + opos; ld = !(a.epi_flag & 1); }
+                            old[r] = (rowp < a.Cout && ld) ? *p[r] : 0.f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const float v = acc[i][q][r] + bv[r];
+                            if (rowp < a.Cout) *p[r] = a.epi == EPI_SUB ? old[r] - v : old[r] + v;
+                        }
+                    }
+                });
+            }
         });
         return;
     }
