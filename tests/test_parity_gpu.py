@@ -106,6 +106,52 @@ def test_bf3_conv_is_as_accurate_as_the_fp32_matrix_core_kernel(case):
     assert np.array_equal(y, y1)
 
 
+def test_bf3_conv_random_shapes_against_float64():
+    """Seeded sweep of odd shapes through the split-bf16 conv (automatic tile, the K-split tile, a phase-merged tile): output
+    channels that are not a multiple of the tile, sequences shorter than one tile or than the halo, every dilation / kernel
+    size the staged window admits, polyphase transposed convs with partial last phases -- against a float64 convolution."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(20260925)
+    cases = []
+    for _ in range(28):
+        ci = int(rng.choice([32, 48, 64, 96, 128, 192, 256]))
+        co = int(rng.integers(1, 300))
+        k = int(rng.integers(1, 14))
+        dil = int(rng.choice([1, 1, 2, 3, 5]))
+        while (k - 1) * dil > 64:
+            k -= 1
+        L = int(rng.choice([1, 2, 7, 31, 33, 127, 129, 257, 700, 3001]))
+        pad = int(rng.integers(0, (k - 1) * dil + 1))
+        if L + 2 * pad - dil * (k - 1) <= 0:
+            pad = dil * (k - 1)
+        cases.append((ci, co, k, pad, dil, L, 0))
+    for _ in range(10):
+        ci = int(rng.choice([32, 64, 128, 256, 512]))
+        co = int(rng.choice([8, 32, 40, 64, 128, 256]))
+        st = int(rng.choice([2, 3, 4, 8]))
+        k = int(st * rng.integers(1, 3) + rng.integers(0, st))
+        L = int(rng.choice([1, 5, 64, 130, 669]))
+        pad = int(rng.integers(0, max(1, (k - st) // 2 + 1)))
+        if (L - 1) * st - 2 * pad + k <= 0:
+            pad = 0
+        cases.append((ci, co, k, pad, 1, L, st))
+    for case in cases:
+        ci, co, k, pad, dil, L, st = case
+        x = (rng.standard_normal((ci, L)) * rng.uniform(0.05, 3.0, (ci, 1))).astype(np.float32)
+        w = (rng.standard_normal((co, k, ci)) / np.sqrt(k * ci)).astype(np.float32)
+        b = rng.standard_normal(co).astype(np.float32)
+        xt = torch.from_numpy(np.where(x < 0, x * np.float32(0.1), x)).double()[None]
+        if st:
+            ref = F.conv_transpose1d(xt, torch.from_numpy(w).double().permute(2, 0, 1).contiguous(), torch.from_numpy(b).double(), stride=st, padding=pad)[0].numpy()
+        else:
+            ref = F.conv1d(xt, torch.from_numpy(w).double().permute(0, 2, 1).contiguous(), torch.from_numpy(b).double(), padding=pad, dilation=dil)[0].numpy()
+        for mode in (13, 40, 42 if st else 24):
+            y = engine.debug_conv1d(x, w, b, pad, dil, st, False, in_slope=0.1, in_act=1, mode=mode)
+            assert y.shape == ref.shape, (case, mode, y.shape, ref.shape)
+            assert np.abs(y - ref).max() <= 2e-5, (case, mode, np.abs(y - ref).max())
+
+
 def test_conv_math_setting_is_validated_and_reported():
     """sts_set_conv_math: 0 / 1 / 2 accepted, anything else EINVAL; the profile reports bf16 matrix-core FLOPs only when the
     trunk ran on split operands (6 x the algorithmic FLOPs), and none under the exact-fp32 setting."""
