@@ -610,6 +610,30 @@ def test_wide_dilation_model_takes_the_checked_paths():
     syn.close()
 
 
+@pytest.mark.parametrize("math", CONV_MATHS)
+@pytest.mark.parametrize("up_init,res_k,res_d", [
+    (256, (5, 9), ((1, 2, 4), (3, 1, 5))),          # stages of 128 / 64 channels: grouped split-bf16 convs + the fused layer kernel
+    (128, (13, 3, 7), ((1, 5, 2), (2, 6, 1), (4, 1, 3))),   # stages of 64 / 32 channels, three chains, halos up to 60 positions
+    (512, (3, 5), ((1, 3, 2), (5, 1, 4))),          # 256 / 128 channels: unfused grouped convs on both stages at this size
+])
+def test_unusual_resblock_geometries_against_the_oracle(up_init, res_k, res_d, math):
+    """ResBlock kernel sizes / dilations / chain counts other than HiFi-GAN's (3, 7, 11) x (1, 3, 5), at the channel widths the
+    fused and grouped trunk kernels are instantiated for, under every trunk arithmetic -- against the C restatement."""
+    import dataclasses
+    cfg = dataclasses.replace(sb.tiny_cfg("hifigan_fix"), up_init=up_init, res_k=res_k, res_d=res_d)
+    blob = sb.make_blob(cfg, 31 + up_init)
+    ids = sb.synthetic_ids(41, cfg.vocab, salt=2)
+    o = pyref.PortModel(blob).infer_ids(ids, 0, 1.0, taps=True)
+    syn = engine.Synthesizer(blob)
+    syn.set_conv_math(math)
+    syn.set_record_taps(True)
+    syn.run_batch([ids])
+    assert (syn.durations(len(ids)) == o["durations"]).all()
+    assert_wave_close(syn.tap("wave")[0], o["wave"], f"resblock geometry {up_init} {res_k}")
+    assert_pcm_close(syn.pcm_host(), o["pcm"], f"resblock geometry {up_init} {res_k}")
+    syn.close()
+
+
 @pytest.mark.parametrize("width", [256, 32])
 def test_fused_column_layers_at_every_instantiated_width(width):
     """col_layer_kernel is instantiated for 32 / 64 / 192 / 256 channels (64 and 192 run in every other test): a model whose
