@@ -79,10 +79,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
 
     const float* w = a.w + (size_t)phase * a.ntap * a.Cin_pad * a.Cout_pad;
     const int mbase = m0 + wm * MW * 32;
-    bool mvalid[MW];
-#pragma unroll
-    for (int i = 0; i < MW; i++) mvalid[i] = (mbase + i * 32) < a.Cout_pad;
-
     f32x16 acc[MW][NW];
 #pragma unroll
     for (int i = 0; i < MW; i++)
@@ -220,56 +216,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
             if (s + u < nsteps) do_step(fa[u % RA], fa[(u + RA - 1) % RA], fb[u % 2], fb[(u + 1) % 2], s + u);
         });
 
-    // ---- epilogue on the accumulator registers -------------------------------------------------
-    // C/D layout of 32x32x2: col (time) = lane & 31, row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int out_off = a.out_off + phase;
+    // ---- epilogue on the accumulator registers (conv_common.hpp: a tile's bias / residual / old values are requested together;
+    // the per-element form this replaces paid one dependent global-load round trip per output element)
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
-    if (a.epi == EPI_GATE) {
-        // rows r and r + 8 of a lane's 16 accumulator rows are tile rows (c, c + 16): the tanh and the sigmoid
-        // pre-activation of one channel (model.hip gate_perm_row)
-        static_for<0, MW>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            static_for<0, NW>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                const int n = n0 + wn * NW * 32 + q * 32 + l31;
-                const int pos = n * a.out_stride + out_off;
-                if (mvalid[i] && n < n_count && pos >= 0 && pos < out_len) {
-                    const size_t opos = out_base + (size_t)pos;
-                    static_for<0, 8>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float vt = acc[i][q][r], vs = acc[i][q][r + 8];
-                        if (a.bias) { vt += a.bias[rowp]; vs += a.bias[rowp + 16]; }
-                        if (a.ubias) { vt += a.ubias[(size_t)rowp * a.ubias_ld + b]; vs += a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b]; }
-                        const int ch = (rowp >> 5) * 16 + (rowp & 15);
-                        if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(vt) * sigmoid_ref(vs);
-                    });
-                }
-            });
-        });
-        return;
-    }
-    static_for<0, MW>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        static_for<0, NW>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            const int n = n0 + wn * NW * 32 + q * 32 + l31;
-            const int pos = n * a.out_stride + out_off;
-            if (mvalid[i] && n < n_count && pos >= 0 && pos < out_len) {
-                const size_t opos = out_base + (size_t)pos;
-                static_for<0, 16>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (rowp < a.Cout) {
-                        float v = acc[i][q][r];
-                        if (a.bias) v += a.bias[rowp];
-                        if (a.ubias) v += a.ubias[(size_t)rowp * a.ubias_ld + b];
-                        epi_scalar(a, rowp, opos, v);
-                    }
-                });
-            }
-        });
-    });
+    tile_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
 }
 
 template <int MW, int NW, int WM, int WN>
@@ -630,11 +580,14 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
         const bool inside = pos >= 0 && pos < len;
         static_for<0, MW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
+            float b1v[16];                               // the lane's 16 bias values, requested together
+#pragma unroll
+            for (int r = 0; r < 16; r++) b1v[r] = a.b1 ? a.b1[mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
             static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[i][r];
-                if (a.b1) v += a.b1[row];
+                if (a.b1) v += b1v[r];
                 v = v < 0.f ? v * G.slope : v;
                 t1[row * RL_W1 + col] = inside ? v : 0.f;
                 acc[i][r] = 0.f;
@@ -695,13 +648,20 @@ __global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(WM == 
             const size_t opos = base + (size_t)pos;
             static_for<0, MW>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                static_for<0, 16>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
+                float b2v[16], xv[16];                   // bias and residual of the lane's 16 rows, requested together
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    b2v[r] = a.b2 ? a.b2[row] : 0.f;
+                    xv[r] = a.x[(size_t)row * G.ld + opos];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
                     const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     float v = acc[i][r];
-                    if (a.b2) v += a.b2[row];
-                    a.y[(size_t)row * G.ld + opos] = v + a.x[(size_t)row * G.ld + opos];
-                });
+                    if (a.b2) v += b2v[r];
+                    a.y[(size_t)row * G.ld + opos] = v + xv[r];
+                }
             });
         }
     }
@@ -861,10 +821,13 @@ void resblock_wino_kernel(ResLayerGroup G, int nx) {
         const int ga = n0 - h2 + pa, gb = n0 - h2 + pb;
         const bool ia = ga >= 0 && ga < len, ib = gb >= 0 && gb < len;
         if (l31 < 30) {
+            float b1v[16];                               // the lane's 16 bias values, requested together
+#pragma unroll
+            for (int r = 0; r < 16; r++) b1v[r] = a.b1 ? a.b1[m0 + (r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
             static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float bv = a.b1 ? a.b1[row] : 0.f;
+                const float bv = b1v[r];
                 float ya = acc[0][r] + acc[1][r] + acc[2][r] + bv;
                 float yb = acc[1][r] - acc[2][r] - acc[3][r] + bv;
                 ya = ya < 0.f ? ya * G.slope : ya;
@@ -943,15 +906,29 @@ void resblock_wino_kernel(ResLayerGroup G, int nx) {
         const int oa = 60 * wn + 2 * l31, ob = oa + 1;
         const bool va = oa < NT && n0 + oa < len, vb = ob < NT && n0 + ob < len;
         const size_t opos = base + (size_t)(n0 + oa);
-        static_for<0, 16>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float bv = a.b2 ? a.b2[row] : 0.f;
-            const float ya = acc[0][r] + acc[1][r] + acc[2][r] + bv;
-            const float yb = acc[1][r] - acc[2][r] - acc[3][r] + bv;
-            const size_t o = (size_t)row * G.ld + opos;
-            if (va) a.y[o] = ya + a.x[o];
-            if (vb) a.y[o + 1] = yb + a.x[o + 1];
+        // bias and residual requested together, 8 rows x 2 positions at a time (the kernel sits at its 128-register budget:
+        // 4 waves per SIMD -- a batch of all 16 rows would cost that)
+        static_for<0, 2>([&](auto hc) {
+            constexpr int hb = decltype(hc)::value * 8;
+            float b2v[8], xa[8], xb[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int row = m0 + ((hb + r) & 3) + 8 * ((hb + r) >> 2) + 4 * half;
+                const size_t o = (size_t)row * G.ld + opos;
+                b2v[r] = a.b2 ? a.b2[row] : 0.f;
+                xa[r] = va ? a.x[o] : 0.f;
+                xb[r] = vb ? a.x[o + 1] : 0.f;
+            }
+            static_for<0, 8>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int row = m0 + ((hb + r) & 3) + 8 * ((hb + r) >> 2) + 4 * half;
+                const float bv = b2v[r];
+                const float ya = acc[0][hb + r] + acc[1][hb + r] + acc[2][hb + r] + bv;
+                const float yb = acc[1][hb + r] - acc[2][hb + r] - acc[3][hb + r] + bv;
+                const size_t o = (size_t)row * G.ld + opos;
+                if (va) a.y[o] = ya + xa[r];
+                if (vb) a.y[o + 1] = yb + xb[r];
+            });
         });
     }
 }

@@ -65,155 +65,6 @@ constexpr int kProdA[6] = {2, 0, 1, 1, 0, 0};
 constexpr int kProdB[6] = {0, 2, 1, 0, 1, 0};
 
 
-// Epilogue on the accumulator registers (C/D layout of every 32x32 MFMA: col (time) = lane & 31,
-// row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)).  The plain and the residual form -- every decoder trunk conv --
-// take a branch-free path: a row tile's 16 bias values and a column tile's 16 residual values are requested together
-// and waited for once.  (Measured: with the per-element epilogue switch each of a lane's 64 outputs paid its own dependent
-// bias load -- ~31 us of a 57 us tile for a 3-tap 128-channel conv.)
-template <int MW, int NW>
-__device__ __forceinline__ void bf3_epilogue(const ConvArgs& a, f32x16 (&acc)[MW][NW], const int mbase, const int ncol0, const int l31,
-                                             const int half, const int n_count, const int out_len, const size_t out_base, const int phase, const int b) {
-    const int out_off = a.out_off + phase;
-    if (a.epi == EPI_STORE || a.epi == EPI_RESADD) {
-        static_for<0, MW>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (mbase + i * 32 < a.Cout_pad) {
-                float bv[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    bv[r] = a.bias ? a.bias[rowp] : 0.f;            // bias is padded to Cout_pad
-                }
-                if (a.ubias) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (rowp < a.Cout) bv[r] += a.ubias[(size_t)rowp * a.ubias_ld + b];
-                    }
-                }
-                static_for<0, NW>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    const int n = ncol0 + q * 32 + l31;
-                    const int pos = n * a.out_stride + out_off;
-                    if (n < n_count && pos >= 0 && pos < out_len) {
-                        const size_t opos = out_base + (size_t)pos;
-                        float rv[16];
-                        if (a.epi == EPI_RESADD) {
-#pragma unroll
-                            for (int r = 0; r < 16; r++) {
-                                const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                                rv[r] = rowp < a.Cout ? a.res[(size_t)rowp * a.res_ld + opos] : 0.f;
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; r++) rv[r] = 0.f;
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            if (rowp < a.Cout) a.y[(size_t)rowp * a.y_ld + opos] = acc[i][q][r] + bv[r] + rv[r];
-                        }
-                    }
-                });
-            }
-        });
-        return;
-    }
-    if (a.epi == EPI_GATE) {
-        // rows r and r + 8 of a lane's 16 accumulator rows are tile rows (c, c + 16): the tanh and the sigmoid pre-activation of one
-        // channel (model.hip gate_perm_row); a row tile's 16 bias values are requested together
-        static_for<0, MW>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (mbase + i * 32 < a.Cout_pad) {
-                float bt[8], bs[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    bt[r] = a.bias ? a.bias[rowp] : 0.f;
-                    bs[r] = a.bias ? a.bias[rowp + 16] : 0.f;
-                    if (a.ubias) { bt[r] += a.ubias[(size_t)rowp * a.ubias_ld + b]; bs[r] += a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b]; }
-                }
-                static_for<0, NW>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    const int n = ncol0 + q * 32 + l31;
-                    const int pos = n * a.out_stride + out_off;
-                    if (n < n_count && pos >= 0 && pos < out_len) {
-                        const size_t opos = out_base + (size_t)pos;
-#pragma unroll
-                        for (int r = 0; r < 8; r++) {
-                            const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const int ch = (rowp >> 5) * 16 + (rowp & 15);
-                            if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(acc[i][q][r] + bt[r]) * sigmoid_ref(acc[i][q][r + 8] + bs[r]);
-                        }
-                    }
-                });
-            }
-        });
-        return;
-    }
-    if (a.epi == EPI_RESSKIP || a.epi == EPI_SUB) {
-        // read-modify-write epilogues of the flow (WN res/skip split, coupling "x1 -= m"): a column tile's 16 old values are
-        // requested together, then updated and stored
-        static_for<0, MW>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (mbase + i * 32 < a.Cout_pad) {
-                float bv[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    bv[r] = a.bias ? a.bias[rowp] : 0.f;
-                    if (a.ubias && rowp < a.Cout) bv[r] += a.ubias[(size_t)rowp * a.ubias_ld + b];
-                }
-                static_for<0, NW>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    const int n = ncol0 + q * 32 + l31;
-                    const int pos = n * a.out_stride + out_off;
-                    if (n < n_count && pos >= 0 && pos < out_len) {
-                        const size_t opos = out_base + (size_t)pos;
-                        float* p[16]; float old[16];
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            bool ld = true;
-                            if (a.epi == EPI_SUB || (a.Cout != a.H && rowp < a.H)) p[r] = a.y + (size_t)rowp * a.y_ld + opos;
-                            else { p[r] = a.aux + (size_t)(a.Cout != a.H ? rowp - a.H : rowp) * a.aux_ld + opos; ld = !(a.epi_flag & 1); }
-                            old[r] = (rowp < a.Cout && ld) ? *p[r] : 0.f;
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const float v = acc[i][q][r] + bv[r];
-                            if (rowp < a.Cout) *p[r] = a.epi == EPI_SUB ? old[r] - v : old[r] + v;
-                        }
-                    }
-                });
-            }
-        });
-        return;
-    }
-    static_for<0, MW>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        static_for<0, NW>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            const int n = ncol0 + q * 32 + l31;
-            const int pos = n * a.out_stride + out_off;
-            if (mbase + i * 32 < a.Cout_pad && n < n_count && pos >= 0 && pos < out_len) {
-                const size_t opos = out_base + (size_t)pos;
-                static_for<0, 16>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (rowp < a.Cout) {
-                        float v = acc[i][q][r];
-                        if (a.bias) v += a.bias[rowp];
-                        if (a.ubias) v += a.ubias[(size_t)rowp * a.ubias_ld + b];
-                        epi_scalar(a, rowp, opos, v);
-                    }
-                });
-            }
-        });
-    });
-}
-
 template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b, const int pm = 0) {
     // pm (polyphase transposed convs): the workgroup's MT rows run over the MERGED row space phase * Cout_pad + row, so that
@@ -416,13 +267,13 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
                     });
                 });
                 static_assert(KG == 1 || NW / KG == 1, "one column tile per group");
-                if (wvalid) bf3_epilogue<MW, NW / KG>(a, mine, mbase, n0 + wn * NW * 32 + g * 32, l31, half, n_count, out_len, out_base, phase, b);
+                if (wvalid) tile_epilogue<MW, NW / KG>(a, mine, mbase, n0 + wn * NW * 32 + g * 32, l31, half, n_count, out_len, out_base, phase, b);
             }
         });
         return;
     }
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
-    if (wvalid) bf3_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
+    if (wvalid) tile_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
 }
 
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
@@ -581,7 +432,7 @@ __device__ __forceinline__ void conv_bf3ws_body(const ConvArgs& a, const int mti
             if (s + u < nsteps) do_step(fa[u % 2], fa[(u + 1) % 2], fb[u % 2], fb[(u + 1) % 2], s + u);
         });
 
-    bf3_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
+    tile_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
 }
 
 template <int MW, int NW, int WM, int WN, int NP, int D>
