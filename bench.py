@@ -115,7 +115,7 @@ def cpu_baseline(blob, vocab, ids, reps: int, sweep):
         try:
             model, kind = pyref.PortModel(blob), "port"
         except Exception:
-            return None
+            return None, None
     nproc = os.cpu_count() or 1
     probe = sb.synthetic_ids(12, vocab, salt=1)
     model.infer_ids(sb.synthetic_ids(6, vocab), 0, 1.0)            # warm-up: OpenMP thread pool, page-in
@@ -147,7 +147,8 @@ def cpu_baseline(blob, vocab, ids, reps: int, sweep):
         n = int(out["wave"].size)
     med = float(np.median(times))
     st = stages[int(np.argsort(times)[len(times) // 2])]
-    return {"value": n / med, "unit": "samples/s", "x_realtime": n / med / 16000.0, "cores": int(best_t), "nproc": nproc,
+    ref_out = {"pcm": out["pcm"], "durations": out["durations"], "wave": out["wave"]} if kind == "reference" else None
+    return ref_out, {"value": n / med, "unit": "samples/s", "x_realtime": n / med / 16000.0, "cores": int(best_t), "nproc": nproc,
             "kind": kind, "phonemes": int(len(ids)), "reps": len(times), "seconds_per_rep_median": med,
             "seconds_per_rep_all": [round(t, 3) for t in times],
             "thread_sweep_samples_per_s": {str(k): round(v, 1) for k, v in sweep_res.items()},
@@ -155,6 +156,75 @@ def cpu_baseline(blob, vocab, ids, reps: int, sweep):
             "sample": f"{len(times)} x 1 utterance of {len(ids)} phonemes (the GPU step's blob and ids) -> {n} samples, "
                       f"median {med:.2f} s, {best_t} OpenMP threads of {nproc} host CPUs "
                       f"({'reference Eigen path, -O3 -fopenmp -std=c++11' if kind == 'reference' else 'C restatement, OpenMP'})"}
+
+
+# BASELINE.json configs[1..4] as bench presets (per-GPU share; weights are seeded synthetic stand-ins at the survey's assumed dims)
+CONFIG_PRESETS = {
+    1: dict(workload="hifigan_sdp", batch=1, phonemes=128, ragged=False,
+            label="configs[1]: single_speaker_fast.bin, batch=1, 128-phoneme synthetic input, 1xMI355X"),
+    2: dict(workload="hifigan_sdp", batch=32, phonemes=128, ragged=True,
+            label="configs[2]: single_speaker_mid.bin, batch=32 utterances of 64-256 phonemes, 1xMI355X"),
+    3: dict(workload="ms_hifigan_sdp", batch=32, phonemes=128, ragged=True,
+            label="configs[3]: multi_speakers.bin (aishell3-like, 174 speakers), mixed-speaker utterances of 64-256 phonemes, 32 per GPU "
+                  "(= the 256-utterance batch at --gpus 8), utterance-sharded, RCCL gather of the int16 PCM"),
+    4: dict(workload="mbb_fix", batch=64, phonemes=128, ragged=True,
+            label="configs[4]: single_speaker_english_fast.bin (MB-iSTFT decoder: iSTFT + PQMF), batch=64 utterances of 64-256 phonemes, 1xMI355X"),
+}
+
+
+def config_label(args) -> str:
+    """Names the BASELINE.json config the flags actually form (or says that they form none)."""
+    for n, pz in CONFIG_PRESETS.items():
+        if (args.workload == pz["workload"] and args.batch == pz["batch"] and bool(args.ragged) == pz["ragged"]
+                and (pz["ragged"] or args.phonemes == pz["phonemes"])):
+            if n == 2 and args.gpus > 1:
+                continue
+            return pz["label"]
+    return (f"custom (no BASELINE.json config): '{args.workload}' blob, batch={args.batch}/GPU, "
+            + ("64..256 phonemes/utterance (ragged)" if args.ragged else f"{args.phonemes} phonemes/utterance"))
+
+
+def parity_report(ref_out, gpu_out):
+    """GPU output of one timed leg against the REAL reference's output for the same blob and ids (the cpu_baseline leg computed
+    it anyway): durations equal?  int16 PCM: max LSB difference and how many samples differ; float waveform RMSE / max-abs."""
+    if ref_out is None or gpu_out is None:
+        return None
+    rp, gp = np.asarray(ref_out["pcm"]).astype(np.int64).ravel(), np.asarray(gpu_out["pcm"]).astype(np.int64).ravel()
+    rep = {"durations_equal": bool(np.array_equal(np.asarray(ref_out["durations"]).ravel(), np.asarray(gpu_out["durations"]).ravel())),
+           "samples_ref": int(rp.size), "samples_gpu": int(gp.size)}
+    if rp.size == gp.size and rp.size:
+        d = np.abs(rp - gp)
+        rep.update(pcm_max_lsb=int(d.max()), pcm_n_off=int((d > 0).sum()))
+        if gpu_out.get("wave") is not None:
+            e = np.asarray(gpu_out["wave"], np.float64).ravel() - np.asarray(ref_out["wave"], np.float64).ravel()
+            rep.update(wave_rmse=float(np.sqrt((e ** 2).mean())), wave_maxabs=float(np.abs(e).max()))
+        rep["ok"] = bool(rep["durations_equal"] and rep["pcm_max_lsb"] <= 1)
+    else:
+        rep["ok"] = False
+    return rep
+
+
+def measured_mfma_ceiling():
+    """Runs tools/ubench/libsts_ubench.so (a bare loop of conv_bf3.hip's 24-MFMA sequence) in THIS process on operands with
+    split-fp32 statistics and on constant operands: what the matrix pipe sustains on this box, now (data-dependent DVFS)."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "ubench", "libsts_ubench.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.sts_ubench_mfma_bf16.restype = ctypes.c_double
+        lib.sts_ubench_mfma_bf16.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        split = float(lib.sts_ubench_mfma_bf16(2, 512, 20000))      # ~20 ms
+        const = float(lib.sts_ubench_mfma_bf16(0, 512, 20000))
+        if split <= 0:
+            return None
+        return {"bf16_tflops_split_fp32_operands": split, "bf16_tflops_constant_operands": const,
+                "tflops_fp32_equivalent": split / BF16_PRODUCTS_PER_F32,
+                "source": "tools/ubench/mfma_bf16_peak.hip run in this process right after the timed legs: 512 workgroups x 4 waves, "
+                          "20 000 x 24 v_mfma_f32_32x32x16_bf16 per wave (~20 ms)"}
+    except Exception:
+        return None
 
 
 def kernel_build_id() -> str:
@@ -168,11 +238,19 @@ def kernel_build_id() -> str:
     return h.hexdigest()[:16]
 
 
+def _env_conv_math() -> str:
+    """STS_CONV_MATH as the engine reads it (f32 / fp32 / 1 = exact-fp32 MFMA, anything else = split-bf16)."""
+    return "f32" if os.environ.get("STS_CONV_MATH", "") in ("f32", "fp32", "1") else "bf16x3"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json configs[N] preset (sets --workload / --batch / --phonemes / --ragged; batch is per GPU, so "
+                         "`--gpus 8 --config 3` is the 256-utterance mixed-speaker batch).  0 = use the individual flags (default = configs[1])")
     ap.add_argument("--workload", default="hifigan_sdp",
                     help="synthetic stand-in for single_speaker_fast.bin: hifigan_sdp (VITS HiFi-GAN + stochastic DP, "
                          "the heavier reading) | mbb_fix | ms_fix | ms_sdp | istft_fix | ms_hifigan_sdp")
@@ -185,7 +263,7 @@ def main():
     ap.add_argument("--cpu-sample-phonemes", type=int, default=0, help="0 = the GPU step's utterance (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=0)
-    ap.add_argument("--conv-math", default=os.environ.get("STS_CONV_MATH", "bf16x3"), choices=["bf16x3", "f32"],
+    ap.add_argument("--conv-math", default=_env_conv_math(), choices=["bf16x3", "f32"],
                     help="arithmetic of the decoder trunk convs: bf16x3 = fp32 operands split exactly into three bf16 terms, six bf16 "
                          "MFMA products per fp32 product, fp32 accumulation (default, same parity tolerances); f32 = the exact-fp32 MFMA")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed leg on the exact-fp32 MFMA path")
@@ -197,6 +275,9 @@ def main():
                          "PCM goes through the host)")
     ap.add_argument("--share-gpu", action="store_true", help="tests only: every rank uses device 0 (needs --backend gloo)")
     args = ap.parse_args()
+    if args.config:
+        pz = CONFIG_PRESETS[args.config]
+        args.workload, args.batch, args.phonemes, args.ragged = pz["workload"], pz["batch"], pz["phonemes"], pz["ragged"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -333,6 +414,25 @@ def main():
     elapsed = time.perf_counter() - t0
     last = syn.profile()
 
+    def capture_output():
+        """One extra UNTIMED run of the step with the float-waveform tap on: utterance 0's durations / PCM / waveform, to be compared
+        with the reference's output for the same blob and ids (parity_report)."""
+        if stub or dist is not None or not ids or not hasattr(syn, "set_record_taps"):
+            return None
+        try:
+            syn.set_record_taps(True)
+            n_out = syn.run_batch(ids, sid, ls)
+            n0, t0_ = int(n_out[0]), len(ids[0])
+            got = {"pcm": syn.pcm_host()[:n0].copy(), "durations": syn.durations(sum(len(a) for a in ids))[:t0_].copy(),
+                   "wave": syn.tap("wave")[0][:n0].copy()}
+            return got
+        except Exception as e:
+            return {"error": str(e)}
+        finally:
+            syn.set_record_taps(False)
+
+    gpu_out = {args.conv_math: capture_output()}
+
     # ---- second timed leg (rank 0, one GPU): the same step with the trunk convs on the exact-fp32 MFMA instruction, so that
     # the line carries both arithmetic paths measured in the same process
     f32_leg = None
@@ -360,7 +460,9 @@ def main():
                    "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": a2 / PEAK_F32_MFMA_TFLOPS, "mfma_issued_tflops": i2,
                                 "mfma_issued_frac": i2 / PEAK_F32_MFMA_TFLOPS}}
+        gpu_out["f32"] = capture_output()
         syn.set_conv_math("bf16x3")
+    ceiling = measured_mfma_ceiling() if (dist is None and not stub and rank == 0) else None
 
     # ---- extra figure (not the headline): the native request pool (sts_pool: N engines, one worker thread each,
     # one FIFO).  "pipelined" = batch-1 requests only overlapped across engines (max_batch 1); "burst" = the same
@@ -458,9 +560,9 @@ def main():
             "data": "synthetic (seeded random weights in the reference .bin grammar; ids[i]=(i*37+11) mod vocab); the reference's "
                     "real .bin models are absent from /root/reference, every number here is on synthetic weights",
             "config": {
-                "workload": f"configs[1]: single_speaker_fast (synthetic '{args.workload}' blob, "
-                            f"{blob.size} floats), batch={args.batch}/GPU, "
-                            + ("64..256 phonemes/utterance (ragged)" if args.ragged else f"{args.phonemes} phonemes/utterance"),
+                "workload": config_label(args) + f" [synthetic '{args.workload}' blob, {blob.size} floats; batch={args.batch}/GPU, "
+                            + ("64..256 phonemes/utterance (ragged)]" if args.ragged else f"{args.phonemes} phonemes/utterance]"),
+                "baseline_config": args.config or next((n for n, pz in CONFIG_PRESETS.items() if config_label(args) == pz["label"]), None),
                 "global_batch": gB, "phonemes": args.phonemes, "frames_per_step_rank0": int(last["frames"]),
                 "samples_per_step_rank0": int(last["samples"]), "parallelism": f"utterance-sharded x{world}",
                 "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("STS_BENCH_SELF_LAUNCHED") else
@@ -485,10 +587,11 @@ def main():
                 "traffic": traffic,
                 "achieved_definition": "ALGORITHMIC (direct-form, true-tap) fp32 FLOPs of the launches / their HIP-event time: the task's "
                                        "roofline figure (SURVEY.md 8d).  It is an effective rate, not pipe utilisation -- see *_issued_*",
-                "sustained_mfma_ceiling": {"tflops_fp32_equivalent": SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32,
-                                           "frac": achieved_tf / (SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32),
-                                           "source": "profiles/r02_mfma_bf16_peak_ubench.log: bare MFMA loop on split-fp32 operand "
-                                                     "statistics, 1712 bf16 TF/s of the nominal 2500 (power management)"} if split else None,
+                "sustained_mfma_ceiling": (dict(ceiling, frac=achieved_tf / ceiling["tflops_fp32_equivalent"], measured=True) if ceiling else
+                                           {"tflops_fp32_equivalent": SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32,
+                                            "frac": achieved_tf / (SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32), "measured": False,
+                                            "source": "tools/ubench/libsts_ubench.so not built: constant from profiles/r02_mfma_bf16_peak_ubench.log "
+                                                      "(1712 bf16 TF/s of the nominal 2500)"}) if split else None,
                 "bf16_issued_tflops": bf16_tf,
                 "bf16_issued_frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
                 "bf16_issued_definition": "bf16 matrix-core FLOPs the split-operand launches issue (6 x their algorithmic FLOPs) / the same "
@@ -523,8 +626,17 @@ def main():
             try:
                 cpu_T = args.cpu_sample_phonemes or (len(ids[0]) if ids else args.phonemes)
                 cpu_ids = ids[0] if (ids and cpu_T == len(ids[0])) else sb.synthetic_ids(cpu_T, cfg.vocab)
-                out["cpu_baseline"] = cpu_baseline(blob, cfg.vocab, cpu_ids, args.cpu_reps,
-                                                   [int(x) for x in args.cpu_threads.split(",") if x])
+                ref_out, out["cpu_baseline"] = cpu_baseline(blob, cfg.vocab, cpu_ids, args.cpu_reps,
+                                                            [int(x) for x in args.cpu_threads.split(",") if x])
+                # parity of the PUBLISHED workload, in the line that publishes it: the reference's output for utterance 0 of this
+                # very step (same blob, same ids) against the GPU output of every timed leg
+                if ref_out is not None and ids and cpu_ids is ids[0] and sid[0] == 0:
+                    par = {}
+                    for leg, g in gpu_out.items():
+                        par[leg] = g if (g is None or "error" in g) else parity_report(ref_out, g)
+                    par["checked"] = (f"utterance 0 of the timed step ({len(cpu_ids)} phonemes, speaker 0) vs the compiled reference "
+                                      "(oracle/_ref) on the same blob and ids; tolerance: durations equal, PCM <= 1 LSB, wave RMSE <= 2e-6")
+                    out["parity"] = par
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": str(e)}
         result_line = json.dumps(out)

@@ -116,6 +116,14 @@ int sts_set_conv_mode(sts_engine* e, int mode);
  *   The default can also be chosen with the environment variable STS_CONV_MATH = bf16x3 | f32. */
 int sts_set_conv_math(sts_engine* e, int mode);
 
+/*   test hooks (per engine, never read from the environment): force a kernel family that the automatic choice would not pick
+ *   at the size of a test.  key: STS_DBG_ATTN_BLOCK_MIN_WGS -- the matrix-core block attention kernel engages from this many
+ *   workgroups on (default 96; 1 = always);  STS_DBG_FRONT_MODE -- text encoder + duration predictor + flow at small batch:
+ *   0 = automatic (single-XCD persistent kernel where it applies), 1 = always one launch per layer, 2 = persistent kernel
+ *   whenever it is eligible, regardless of the batch size. */
+enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2 };
+int sts_debug_set(sts_engine* e, int key, int value);
+
 /* Per-stage device timing of the last run, measured with HIP events on the engine's own stream. */
 typedef struct sts_profile {
     float ms_text_encoder, ms_duration, ms_flow, ms_decoder, ms_total_device;

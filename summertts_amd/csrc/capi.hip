@@ -145,6 +145,14 @@ int sts_set_conv_math(sts_engine* e, int mode) {
     return STS_OK;
 }
 int sts_set_conv_mode(sts_engine* e, int mode) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.conv_mode = mode; return STS_OK; }
+int sts_debug_set(sts_engine* e, int key, int value) {
+    if (!e) return set_err(STS_EINVAL, "null engine");
+    switch (key) {
+        case STS_DBG_ATTN_BLOCK_MIN_WGS: if (value < 1) return set_err(STS_EINVAL, "threshold must be >= 1"); e->eng.attn_block_min_wgs = value; return STS_OK;
+        case STS_DBG_FRONT_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "front mode must be 0, 1 or 2"); e->eng.front_mode = value; return STS_OK;
+        default: return set_err(STS_EINVAL, "unknown debug key");
+    }
+}
 int sts_set_host_pcm(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.host_pcm = enable != 0; return STS_OK; }
 int sts_set_profiling(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.profiling = enable != 0; return STS_OK; }
 

@@ -26,6 +26,7 @@
 #include "kernels.hpp"
 #include "devmath.hpp"
 #include "conv_common.hpp"
+#include "knobs.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -281,173 +282,6 @@ __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_e
     const TileId t = map_tile(nx, ny, a.B);
     if (!t.valid) return;
     conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(a, mtiles, t.bx, t.by, t.bz, pm);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Wave-specialised form of the same conv.  Measured on the kernel above (SQ counters): its waves sit
-// parked half of the time, because vmcnt retires IN ORDER -- every weight fragment requested after a chunk's input
-// loads waits for those loads (HBM latency), so a few-tap conv stalls once per chunk no matter how far ahead the input
-// was requested.  Here the two streams live in different waves:
-//   * NP PRODUCER waves own the input: they keep D chunks of raw loads in flight in their registers (they need no
-//     accumulators), apply the activation, split, and publish one chunk per barrier;
-//   * WM x WN CONSUMER waves see nothing but weight-fragment loads, LDS reads and MFMAs.
-// One s_barrier per 16-channel chunk couples them (chunk c is written while chunk c - 1 is read: two LDS buffers).
-// ------------------------------------------------------------------------------------------------
-template <int MW, int NW, int WM, int WN, int NP, int D>
-__device__ __forceinline__ void conv_bf3ws_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
-    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NC = WM * WN;
-    constexpr int WIN = NT + MAX_HALO, NSLOT = WIN / 32;
-    constexpr int SPP = (NSLOT + NP - 1) / NP;          // slots per producer wave
-    constexpr int PLANE = WIN * 32, BUF = 3 * PLANE;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    const int in_len = seg_len(a.in_seg, b);
-    const int out_len = seg_len(a.out_seg, b);
-    const int n_count = a.transposed ? in_len + a.n_extra : out_len;
-    const int n0 = bx * NT;
-    if (n0 >= n_count) return;
-    const int phase = by / mtiles;
-    const int m0 = (by - phase * mtiles) * MT;
-    const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int swave = __builtin_amdgcn_readfirstlane(wave);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
-    const int lo = first < last ? first : last, hi = first < last ? last : first;
-    const int W = NT + (hi - lo);
-    const int win0 = n0 + lo;
-    const int nchunk = a.Cin_pad / CK;
-
-    if (swave >= NC) {
-        // ======================= producer =======================
-        const int pw = swave - NC;
-        unsigned xoff[SPP]; int lds_w[SPP]; bool sact[SPP];
-        const unsigned ld4 = (unsigned)a.x_ld * 4u;
-#pragma unroll
-        for (int i = 0; i < SPP; i++) {
-            const int slot = pw + i * NP;
-            const int col = slot * 32 + l31;
-            const int pos = win0 + col;
-            sact[i] = slot < NSLOT && slot * 32 < W;
-            const bool v = col < W && pos >= 0 && pos < in_len;
-            xoff[i] = v ? (unsigned)half * 8u * ld4 + (unsigned)pos * 4u : kOOB;
-            lds_w[i] = col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
-        }
-        float xr[D][SPP][8];
-        // every load is unconditional (inactive slots and chunks past the end read 0 through an out-of-range offset / an empty
-        // descriptor): with no branch around a load the compiler knows how many are in flight and waits with vmcnt(N) for
-        // the oldest chunk only -- the other D - 1 chunks stay in flight
-        auto load_x = [&](int c, float (&dst)[SPP][8]) {
-            const rsrc_t rs = make_rsrc(a.x + (size_t)c * CK * a.x_ld + in_base, c < nchunk ? (unsigned)((15ul * a.x_ld + in_len) * 4ul) : 0u);
-#pragma unroll
-            for (int i = 0; i < SPP; i++)
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                    dst[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)xoff[i], (int)((unsigned)e * ld4), 0));
-        };
-        auto store_tile = [&](int bufi, float (&src)[SPP][8]) {
-            unsigned char* sb = smem3 + bufi * BUF;
-#pragma unroll
-            for (int i = 0; i < SPP; i++) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) { v[e] = src[i][e]; if (a.in_act) v[e] = v[e] < 0.f ? v[e] * a.in_slope : v[e]; }
-                u32x4 ph, pm, pl;
-                split8(v, ph, pm, pl);
-                if (sact[i]) {
-                    *(u32x4*)(sb + lds_w[i]) = ph;
-                    *(u32x4*)(sb + PLANE + lds_w[i]) = pm;
-                    *(u32x4*)(sb + 2 * PLANE + lds_w[i]) = pl;
-                }
-            }
-        };
-        static_for<0, D>([&](auto dc) { constexpr int dd = decltype(dc)::value; load_x(dd, xr[dd]); });
-        for (int c = 0; c < nchunk; c += D)
-            static_for<0, D>([&](auto dc) {
-                constexpr int dd = decltype(dc)::value;
-                const bool live = c + dd < nchunk;
-                if (live) store_tile((c + dd) & 1, xr[dd]);   // the buffer's previous chunk was consumed before the last barrier
-                load_x(c + dd + D, xr[dd]);
-                if (live) __syncthreads();                     // barrier c + dd: chunk published
-            });
-        return;
-    }
-
-    // ======================= consumers =======================
-    const int wm = swave / WN, wn = swave - wm * WN;
-    const int mbase = m0 + wm * MW * 32;
-    f32x16 acc[MW][NW];
-#pragma unroll
-    for (int i = 0; i < MW; i++)
-#pragma unroll
-        for (int j = 0; j < NW; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int nsteps = nchunk * a.ntap;
-    const int nrt = a.Cout_pad / 32;
-    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps * nrt * 3072));
-    const unsigned a_voff = (unsigned)lane * 16u;
-    const unsigned a_s0 = ((unsigned)phase * (unsigned)nsteps * (unsigned)nrt + (unsigned)(mbase >> 5)) * 3072u;   // scalar: swave is
-    const unsigned a_step = (unsigned)nrt * 3072u;
-    auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
-        const unsigned sb = a_s0 + (unsigned)s * a_step;
-#pragma unroll
-        for (int i = 0; i < MW; i++)
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++)
-                dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
-    };
-    const int b_t0 = wn * NW * 32 + l31 + a.tap_off - lo;
-    auto load_b = [&](int bufi, int j, u32x4 (&dst)[NW][3]) {
-        const int t = b_t0 + j * a.tap_step;
-        const unsigned char* sb = smem3 + bufi * BUF + t * 32 + ((half ^ ((t >> 3) & 1)) << 4);
-#pragma unroll
-        for (int q = 0; q < NW; q++)
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE + q * 1024);
-    };
-    constexpr int RA = 2;
-    u32x4 fa[RA][MW][3], fb[2][NW][3];
-    int sj = 0, sc = 0, as = 0;
-    auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
-        int nj = sj + 1, nc = sc;
-        if (nj == a.ntap) { nj = 0; nc = sc + 1; }
-        load_a(as++, anew);
-        if (nc != sc && nc < nchunk) __syncthreads();      // barrier nc: chunk nc published (and nobody still reads chunk nc - 2's buffer)
-        load_b(nc & 1, nj, bnxt);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 6; p++)
-#pragma unroll
-            for (int i = 0; i < MW; i++)
-#pragma unroll
-                for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(acur[i][kProdA[p]], bcur[q][kProdB[p]], acc[i][q]);
-        sj = nj; sc = nc;
-    };
-    load_a(as++, fa[0]);
-    __syncthreads();                                       // barrier 0
-    load_b(0, 0, fb[0]);
-    for (int s = 0; s < nsteps; s += 2)
-        static_for<0, 2>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            if (s + u < nsteps) do_step(fa[u % 2], fa[(u + 1) % 2], fb[u % 2], fb[(u + 1) % 2], s + u);
-        });
-
-    tile_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
-}
-
-template <int MW, int NW, int WM, int WN, int NP, int D>
-__global__ __launch_bounds__((WM * WN + NP) * 64) __attribute__((amdgpu_waves_per_eu(1, 3))) void conv_bf3ws_kernel(ConvArgs a, int mtiles, int nx, int ny) {
-    const TileId t = map_tile(nx, ny, a.B);
-    if (!t.valid) return;
-    conv_bf3ws_body<MW, NW, WM, WN, NP, D>(a, mtiles, t.bx, t.by, t.bz);
-}
-template <int MW, int NW, int WM, int WN, int NP, int D>
-__global__ __launch_bounds__((WM * WN + NP) * 64) __attribute__((amdgpu_waves_per_eu(1, 3))) void conv_bf3ws_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny) {
-    const TileId t = map_tile(nx, ny, B * G.n);
-    if (!t.valid) return;
-    const int gi = t.bz / B;
-    const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_bf3ws_body<MW, NW, WM, WN, NP, D>(ga[gi], mtiles, t.bx, t.by, t.bz - gi * B);
 }
 
 // grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
@@ -746,7 +580,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
 constexpr int kNumBf3Tiles = 6;
-static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 16 && tile < 25); }
+static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 20 && tile < 25); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
     if (!a.wb3 || a.depthwise || a.in_reflect) return false;
@@ -805,34 +639,13 @@ static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT;
     const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG>();
-    static const int il = getenv("STS_BF3_INTERLEAVE") ? atoi(getenv("STS_BF3_INTERLEAVE")) : 0;   // experiment knob
+    static const int il = exp_int("STS_BF3_INTERLEAVE", 0);
     hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * KG * 64), lds, st, G,
                        mt, a.B, nx, mt, il & 1);
 }
 
 // 20: 128 x 128 with K split over two wave groups inside the workgroup (8 waves, 32-channel staged chunks)
 // 24: 256 x 64, K split over two wave groups (8 waves): all rows of a 256-channel conv behind ONE staged window
-// wave-specialised tiles: 16: 128 x 128 (4 consumer waves of 64 x 64 + 2 producers)   17: 64 x 128 (2 + 1)
-//                         18: 128 x 256 (8 + 2)                                        19: 64 x 256 (4 + 2)
-template <int MW, int NW, int WM, int WN, int NP, int D>
-static void launch_bf3ws(const ConvArgs& a, int nphase, hipStream_t st) {
-    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
-    const int mt = (a.Cout_pad + MT - 1) / MT;
-    const int nx = (a.max_n + NT - 1) / NT, ny = mt * nphase;
-    const size_t lds = (size_t)6 * (NT + MAX_HALO) * 32;
-    hipLaunchKernelGGL((conv_bf3ws_kernel<MW, NW, WM, WN, NP, D>), dim3(mapped_grid(nx, ny, a.B)), dim3((WM * WN + NP) * 64), lds, st, a, mt, nx, ny);
-}
-template <int MW, int NW, int WM, int WN, int NP, int D>
-static void launch_bf3ws_group(const ConvGroup& G, hipStream_t st) {
-    constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
-    const ConvArgs& a = G.g[0];
-    const int mt = (a.Cout_pad + MT - 1) / MT;
-    const int nx = (a.max_n + NT - 1) / NT;
-    const size_t lds = (size_t)6 * (NT + MAX_HALO) * 32;
-    hipLaunchKernelGGL((conv_bf3ws_group_kernel<MW, NW, WM, WN, NP, D>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3((WM * WN + NP) * 64), lds, st, G,
-                       mt, a.B, nx, mt);
-}
-
 long conv_bf3_blocks(const ConvArgs& a) {
     const int nphase = a.transposed ? a.out_stride : 1;
     const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
@@ -852,10 +665,6 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
         case 21: launch_bf3<2, 2, 4, 2, 1>(a, nphase, st, 1); break;
         case 22: launch_bf3<2, 2, 2, 2, 1>(a, nphase, st, 1); break;
         case 23: launch_bf3<1, 2, 2, 2, 1>(a, nphase, st, 1); break;
-        case 16: launch_bf3ws<2, 2, 2, 2, 2, 3>(a, nphase, st); break;
-        case 17: launch_bf3ws<2, 2, 1, 2, 1, 2>(a, nphase, st); break;
-        case 18: launch_bf3ws<2, 2, 2, 4, 2, 3>(a, nphase, st); break;
-        case 19: launch_bf3ws<2, 2, 1, 4, 2, 3>(a, nphase, st); break;
         case 0: launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
         case 1: launch_bf3<2, 2, 1, 4, 1>(a, nphase, st); break;
         case 2: launch_bf3<2, 2, 2, 4, 1>(a, nphase, st); break;
@@ -897,10 +706,6 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
                    if (ok) launch_bf3_group<2, 2, 2, 2, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
         case 24: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
                    if (ok) launch_bf3_group<2, 2, 4, 1, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
-        case 16: launch_bf3ws_group<2, 2, 2, 2, 2, 3>(G, st); break;
-        case 17: launch_bf3ws_group<2, 2, 1, 2, 1, 2>(G, st); break;
-        case 18: launch_bf3ws_group<2, 2, 2, 4, 2, 3>(G, st); break;
-        case 19: launch_bf3ws_group<2, 2, 1, 4, 2, 3>(G, st); break;
         case 0: launch_bf3_group<2, 2, 2, 2, 1>(G, st); break;
         case 1: launch_bf3_group<2, 2, 1, 4, 1>(G, st); break;
         case 2: launch_bf3_group<2, 2, 2, 4, 1>(G, st); break;
@@ -942,7 +747,7 @@ static void launch_resblock_bf3(const ResLayerGroup& G, hipStream_t st) {
     const int wst = (P1 + halo + 31) / 32 * 32;
     const size_t stage = (size_t)C * wst * 6, park = (size_t)C * P1 * 6 + 1024;    // + slack: conv2's taps of the discarded last columns
     const size_t lds = stage > park ? stage : park;
-    static const int il = getenv("STS_BF3_INTERLEAVE") ? atoi(getenv("STS_BF3_INTERLEAVE")) : 0;   // experiment knob
+    static const int il = exp_int("STS_BF3_INTERLEAVE", 0);
     hipLaunchKernelGGL((resblock_bf3_kernel<MW, WM, NW, WN>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx, wst, (il >> 1) & 1);
 }
 

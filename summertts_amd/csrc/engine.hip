@@ -5,12 +5,14 @@
 // Everything runs on the engine's own HIP stream; the only host synchronisation inside a run is the
 // data-dependent frame count F (SynthesizerTrn.cpp:376-381).
 #include "engine.hpp"
+#include "knobs.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 
 namespace sts {
 
@@ -143,12 +145,16 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     if (conv_mode == 0 && conv_math != 1 && o.tile < 0 && conv_bf3_eligible(a) &&
         (in_mfma_region_ || conv_math == 2 || conv_bf3_blocks(a) >= 384)) {
         if (in_mfma_region_) { mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_++; }
-        static const int bt = getenv("STS_BF3_TILE") ? atoi(getenv("STS_BF3_TILE")) : -1;   // experiment knob
+        static const int bt = exp_int("STS_BF3_TILE", -1);   // experiment knob
         conv_bf3(a, cur_, bt);
     } else if (can_mfma) {
         if (in_mfma_region_) { mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_++; }
         conv_mfma(a, cur_, o.tile >= 0 ? o.tile : (conv_mode >= 2 ? conv_mode - 2 : -1));
     } else {
+        // the generic kernel knows nothing of cross-workgroup K slices: it writes the complete sum into slice 0, so the
+        // consumer's other partial operands must read as zero
+        if (a.kslices > 1 && a.kslice_stride > 0)
+            (void)hipMemsetAsync(a.y + a.kslice_stride, 0, (size_t)(a.kslices - 1) * (size_t)a.kslice_stride * sizeof(float), cur_);
         conv_generic(a, cur_);
     }
 }
@@ -182,7 +188,7 @@ void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, 
 // pre_in == null: the all-zero latent).  Where the first layer runs fused, h is never materialised: the kernel evaluates it at its
 // depthwise taps; otherwise the conv runs first, into `h`.
 float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre, const float* pre_in, const float* pre_res) {
-    static const bool no_col = getenv("STS_NO_COL_LAYER") != nullptr;   // experiment knob
+    static const bool no_col = exp_flag("STS_NO_COL_LAYER");   // experiment knob
     float* cur = h;
     bool pre_pending = pre != nullptr;
     auto run_pre = [&]() {      // the unfused form of the input conv (zero input: a memset feeds it)
@@ -370,7 +376,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     HIPCK(hipMemcpyAsync(bt.meta_i, pm, (meta_ints + B + (size_t)Ttot * (have_forced ? 2 : 1)) * 4, hipMemcpyHostToDevice, stream));
 
     // single-segment views travel by value (kernels.hpp SegView): no segment-table load in the kernels of a one-utterance call
-    static const bool no_inline_seg = getenv("STS_NO_INLINE_SEG") != nullptr;   // experiment knob
+    static const bool no_inline_seg = exp_flag("STS_NO_INLINE_SEG");   // experiment knob
     const bool inl = B == 1 && !no_inline_seg;
     lvT.seg = inl ? SegView{nullptr, nullptr, 1, 0, 0, lenT[0]} : SegView{d_offT, d_lenT, 1, 0, 0, 0};
     Lvl lvB; lvB.seg = no_inline_seg ? SegView{d_one, d_one + 1, 1, 0, 0, 0} : SegView{nullptr, nullptr, 1, 0, 0, B};
@@ -382,7 +388,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     // The producer of a layer's input x -- the embedding for layer 0, the previous layer's second LayerNorm (which also adds
     // the FFN's split-K partials) afterwards -- runs inside the launch of the first conv that consumes x (col_proj_kernel)
     // where the width is instantiated and the grid is small; otherwise as its own launch.
-    static const bool no_colp = getenv("STS_NO_COL_LAYER") != nullptr || getenv("STS_NO_COL_PROJ") != nullptr;   // experiment knobs
+    static const bool no_colp = exp_flag("STS_NO_COL_LAYER") || exp_flag("STS_NO_COL_PROJ");   // experiment knobs
     // Measured (profiles/r02 notes in DESIGN.md 5b): with a handful of column blocks (one 128-phoneme utterance = 8) a
     // three-pass q/k/v projection makes each of the few workgroups pull 3 x 147 KB of weights through one CU and loses to
     // the separate LayerNorm + chip-wide conv (23 vs 18 us); from a few dozen blocks on it wins (batch 8: -12 us per layer).
@@ -417,12 +423,12 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         memset(&at, 0, sizeof(at));
         at.q = bt.qkv; at.k = bt.qkv + (size_t)H * Ttot; at.v = bt.qkv + (size_t)2 * H * Ttot; at.o = bt.att; at.ld = Ttot;
         at.relk = a.relk; at.relv = a.relv; at.kc = a.kc; at.px = a.px; at.win = a.win; at.nheads = 2;
-        at.seg = lvT.seg; at.B = B; at.max_len = maxT;
+        at.seg = lvT.seg; at.B = B; at.max_len = maxT; at.block_min_wgs = attn_block_min_wgs;
         attention(at, stream);
         flops_[0] += 2.0 * 2.0 * (double)a.ch * (double)maxT * (double)Ttot;   // ~ QK^T + PV
         bytes_[0] += 4.0 * 4.0 * (double)H * (double)Ttot;                       // q, k, v in; o out
         {   // output projection + residual + LayerNorm: one launch (col_layer.hip) where the width is instantiated
-            static const bool no_col = getenv("STS_NO_COL_LAYER") != nullptr;   // experiment knob
+            static const bool no_col = exp_flag("STS_NO_COL_LAYER");   // experiment knob
             ColLayerArgs g;
             memset(&g, 0, sizeof(g));
             g.x = bt.att; g.x_ld = Ttot; g.wc = a.o.wc; g.bias = a.o.bias;
@@ -498,7 +504,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     // ---------------- the one data-dependent sync: frame counts (+ durations for the API).  The durations kernel writes them
     // straight into host-mapped pinned memory and raises a sequence flag; the host polls that word -- no device-to-host copy
     // kernel and no stream-synchronise wake-up between the duration predictor and the flow (STS_NO_MAPPED_SYNC=1: the copy path)
-    static const bool no_mapped = getenv("STS_NO_MAPPED_SYNC") != nullptr;
+    static const bool no_mapped = exp_flag("STS_NO_MAPPED_SYNC");
     const size_t hm_ints = (size_t)Ttot + B + 1;
     if (!no_mapped && hm_ints > hmap_cap_) {
         (void)hipStreamSynchronize(stream);
@@ -521,12 +527,21 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         if (mapped) {
             volatile int* flag = hmap_;                 // word 0 = sequence flag, then dur[Ttot], frames[B]
             bool ok = false;
+            // a short pure spin (the usual wait is a fraction of a millisecond), then polite polling -- pool / multi-device
+            // workers must not each burn a core for a whole batch --, and after 50 ms a plain stream synchronisation
             for (long spin = 0; ; spin++) {
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_) { ok = true; break; }
+                __builtin_ia32_pause();
+                if (spin >= 20000) std::this_thread::yield();
                 if ((spin & 0x3ff) == 0x3ff) {      // every ~1k polls: did the stream die?  (a kernel fault would spin forever)
                     const hipError_t q = hipStreamQuery(stream);
                     if (q == hipSuccess) { ok = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_; break; }
                     if (q != hipErrorNotReady) return fail(STS_EDEVICE, std::string("stream failed before the frame counts arrived: ") + hipGetErrorString(q));
+                    if (std::chrono::steady_clock::now() - w0 > std::chrono::milliseconds(50)) {
+                        HIPCK(hipStreamSynchronize(stream));
+                        ok = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_;
+                        break;
+                    }
                 }
             }
             if (!ok) return fail(STS_EDEVICE, "frame counts did not arrive");
@@ -610,7 +625,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         float* dst = bf.z + (size_t)(cp.flipped ? 0 : half) * Ftot;
         const DWn& w = cp.wn;
         if (w.has_cond) conv(w.cond, bt.g, lvB, bt.cond_wn, lvB, ConvOpt());
-        static const int flow_1x1_tile = getenv("STS_FLOW_1X1_TILE") ? atoi(getenv("STS_FLOW_1X1_TILE")) : -1;   // experiment knob
+        static const int flow_1x1_tile = exp_int("STS_FLOW_1X1_TILE", -1);   // experiment knob
         { ConvOpt op; op.tile = flow_1x1_tile; conv(cp.pre, x0, lv1, bf.h, lv1, op); }
         for (int l = 0; l < w.n; l++) {
             ConvOpt og; og.epi = EPI_GATE;
@@ -663,7 +678,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         float* bup = reg;
         ConvOpt ou; ou.in_act = 1; ou.slope = 0.1f;
         {   // experiment knob: per-stage kernel variant of the upsamplers, e.g. STS_UP_TILE=6--- (digit = conv mode - 2, '-' = automatic)
-            static const char* ut = getenv("STS_UP_TILE");
+            static const char* ut = exp_env("STS_UP_TILE");
             if (ut && (int)strlen(ut) > i && ut[i] >= '0' && ut[i] <= '7') ou.tile = ut[i] - '0';
         }
         conv(up, x, lx, bup, l2, ou);
@@ -689,7 +704,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
             for (int j = 0; j < nk; j++) cur[j] = bup;
             // experiment knob STS_CHAIN_STREAMS=<stage mask>: the chains of the masked stages go out as per-chain launches on
             // the prioritised auxiliary streams (heaviest chain first) instead of one grouped launch per layer
-            static const int chain_streams = getenv("STS_CHAIN_STREAMS") ? atoi(getenv("STS_CHAIN_STREAMS")) : 0;
+            static const int chain_streams = exp_int("STS_CHAIN_STREAMS", 0);
             const bool per_chain = ((chain_streams >> i) & 1) && nk <= kAux;
             int crank[kMaxGroup];
             for (int j = 0; j < nk; j++) {
@@ -703,21 +718,21 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                 (void)hipEventRecord(ev_fork_, stream);
                 for (int k = 0; k < kAux; k++) (void)hipStreamWaitEvent(aux_[k], ev_fork_, 0);
             }
-            static const bool no_fuse = getenv("STS_NO_FUSE") != nullptr;   // experiment knob
+            static const bool no_fuse = exp_flag("STS_NO_FUSE");   // experiment knob
             for (int d = 0; d < nd0; d++) {
                 // narrow stages: the whole layer (conv1 -> lrelu -> conv2 -> + x) of all chains in one launch
                 ResLayerGroup R;
                 memset(&R, 0, sizeof(R));
                 R.n = nk; R.C = up.Cout; R.ld = l2.ld; R.slope = 0.1f; R.seg = l2.seg; R.B = l2.nb; R.max_n = l2.max_len;
-                static const int fuse_maxc = getenv("STS_FUSE_MAXC") ? atoi(getenv("STS_FUSE_MAXC")) : 128;   // experiment knob
+                static const int fuse_maxc = exp_int("STS_FUSE_MAXC", 128);   // experiment knob
                 bool fuse = !no_fuse && R.C <= fuse_maxc;
-                static const bool bf3_nofuse = getenv("STS_BF3_NOFUSE") != nullptr;   // experiment knob
+                static const bool bf3_nofuse = exp_flag("STS_BF3_NOFUSE");   // experiment knob
                 const bool bf3_layer = (conv_math != 1) && !bf3_nofuse;
                 // split-bf16 arithmetic: the 64/32-channel stages always run fused; the 128-channel stage (whole window = 147 KB of
                 // LDS, one 8-wave workgroup per CU) from ~8 tiles per CU on -- the trunk is power-bound at batch, so
                 // dropping the intermediate's HBM round trip pays (batch 8: -3 %), while a single utterance's 1 089 tiles on 256
                 // workgroup slots only tie the unfused pair
-                static const int bf3_fuse128_tiles = getenv("STS_BF3_FUSE128_TILES") ? atoi(getenv("STS_BF3_FUSE128_TILES")) : 2048;   // experiment knob
+                static const int bf3_fuse128_tiles = exp_int("STS_BF3_FUSE128_TILES", 2048);   // experiment knob
                 if (conv_math != 1) {
                     if (bf3_nofuse || R.C > 128) fuse = false;
                     else if (R.C > 64) fuse = fuse && (long)((l2.max_len + 117) / 118) * l2.nb * nk >= bf3_fuse128_tiles;
@@ -750,10 +765,10 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     }
                     // both convs in the Winograd domain when the model carries the transformed weights (-31 % MFMAs);
                     // the direct-form fused kernel otherwise
-                    static const bool no_wino = getenv("STS_NO_WINO") != nullptr;   // experiment knob
+                    static const bool no_wino = exp_flag("STS_NO_WINO");   // experiment knob
                     const bool wino = !no_wino && resblock_wino_eligible(R);
                     if (bf3_layer && resblock_bf3_eligible(R)) {
-                        static const int bv = getenv("STS_BF3_LAYER_VARIANT") ? atoi(getenv("STS_BF3_LAYER_VARIANT")) : -1;   // experiment knob
+                        static const int bv = exp_int("STS_BF3_LAYER_VARIANT", -1);   // experiment knob
                         resblock_bf3(R, stream, bv);
                         mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_ += 1;
                         continue;
@@ -780,7 +795,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     G2.g[j] = conv_args(rb.c2[d], t1, l2, nxt, l2, o2, &f); fl2 += f;
                     cur[j] = nxt;
                 }
-                static const char* gt = getenv("STS_GROUP_TILE");   // experiment knob: per-stage tile digits, e.g. "4335"
+                static const char* gt = exp_env("STS_GROUP_TILE");   // experiment knob: per-stage tile digits, e.g. "4335"
                 const int gtile = gt && (int)strlen(gt) > i ? gt[i] - '0' : -1;
                 // every layer is checked on its own: later layers have larger dilations, and a halo beyond the staged
                 // LDS window (e.g. k = 11 with dilation 7) must take the per-conv path, which falls back to conv_generic
@@ -794,7 +809,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
                     continue;
                 }
                 if ((conv_math != 1) && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
-                    static const char* bgt = getenv("STS_BF3_GROUP_TILE");   // experiment knob: per-stage tile digits
+                    static const char* bgt = exp_env("STS_BF3_GROUP_TILE");   // experiment knob: per-stage tile digits
                     const int bt = bgt && (int)strlen(bgt) > i ? (bgt[i] >= '0' && bgt[i] <= '9' ? bgt[i] - '0' : (bgt[i] >= 'a' && bgt[i] <= 'z' ? bgt[i] - 'a' + 10 : -1)) : -1;
                     conv_bf3_group(G1, stream, bt);
                     conv_bf3_group(G2, stream, bt);

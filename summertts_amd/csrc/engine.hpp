@@ -70,6 +70,8 @@ public:
     bool record_taps = false, profiling = false;
     int conv_mode = 0;
     int conv_math = 0;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA (sts_set_conv_math)
+    int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
+    int front_mode = 0;                // 0 automatic, 1 one launch per layer, 2 persistent single-XCD kernel wherever eligible (sts_debug_set)
     hipStream_t stream = nullptr;
 
 private:

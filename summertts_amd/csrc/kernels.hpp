@@ -132,6 +132,7 @@ struct AttnArgs {
     const float* relk; const float* relv;   // [kc][px] (reference column-major [px, kc])
     int kc, px, win, nheads;
     SegView seg; int B, max_len;
+    int block_min_wgs;              // the 16-queries-per-workgroup matrix-core kernel from this many workgroups on (0: default 96)
 };
 
 // ---- launchers (all asynchronous on `st`) ------------------------------------------------------

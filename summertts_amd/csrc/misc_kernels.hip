@@ -4,6 +4,7 @@
 // wave64 shuffles; every kernel reads/writes time-contiguous rows so global accesses coalesce.
 #include "kernels.hpp"
 #include "devmath.hpp"
+#include "knobs.hpp"
 #include <stdlib.h>
 
 namespace sts {
@@ -404,15 +405,14 @@ static size_t attention_mfma_lds(const AttnArgs& a, int Tpad) {
 void attention(const AttnArgs& a, hipStream_t st) {
     if (a.max_len <= 0 || a.B <= 0) return;
     {   // matrix-core form: 16 queries per workgroup, whenever its LDS footprint fits and the model shape is covered
-        static const bool no_mfma = getenv("STS_NO_ATTN_MFMA") != nullptr;   // experiment knob
+        static const bool no_mfma = exp_flag("STS_NO_ATTN_MFMA");   // experiment knob
         const int Tpad = (a.max_len + 63) / 64 * 64;
         const size_t lds = attention_mfma_lds(a, Tpad);
         // Measured: the block kernel is one long dependent chain per workgroup -- with 16 workgroups (one
         // 128-phoneme utterance) it takes 26 us against 11.5 us for the one-query-per-workgroup kernel; from about a
         // hundred workgroups on it wins (batch 8: 98 -> 45 us per launch, text encoder 1.21 -> 0.88 ms)
         const long wgs = (long)((a.max_len + 15) / 16) * a.nheads * a.B;
-        const char* mw = getenv("STS_ATTN_MFMA_MIN_WGS");       // test / experiment knob (read per call): threshold override
-        const long min_wgs = mw ? atol(mw) : 96;
+        const long min_wgs = a.block_min_wgs > 0 ? a.block_min_wgs : 96;
         if (!no_mfma && wgs >= min_wgs && a.kc % 16 == 0 && a.kc <= 128 && a.px <= 32 && lds <= 150 * 1024) {
             if (lds > 48 * 1024)
                 hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -150,7 +150,8 @@ int sts_multi_shard_of(const sts_multi* m, int32_t B, const int32_t* n, int32_t*
 int sts_multi_infer_ids_batch(sts_multi* m, int32_t B, const int32_t* const* ids, const int32_t* n, const int32_t* sid,
                               const float* length_scale, int16_t** pcm_out, int32_t* n_out) {
     if (!m || !ids || !n || !pcm_out || !n_out || B <= 0) return multi_err(STS_EINVAL, "bad arguments");
-    for (int b = 0; b < B; b++) { pcm_out[b] = nullptr; n_out[b] = 0; if (n[b] <= 0 || !ids[b]) return multi_err(STS_EINVAL, "utterance with no phonemes"); }
+    for (int b = 0; b < B; b++) { pcm_out[b] = nullptr; n_out[b] = 0; }      // every output is defined before the first early return
+    for (int b = 0; b < B; b++) if (n[b] <= 0 || !ids[b]) return multi_err(STS_EINVAL, "utterance with no phonemes");
     const int ndev = (int)m->engines.size();
     {
         std::unique_lock<std::mutex> lk(m->mu);

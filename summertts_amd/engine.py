@@ -71,6 +71,7 @@ def load_library() -> C.CDLL:
     lib.sts_set_record_taps.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_conv_mode.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_conv_math.argtypes = [C.c_void_p, C.c_int]
+    lib.sts_debug_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.sts_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_host_pcm.argtypes = [C.c_void_p, C.c_int]
     lib.sts_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
@@ -91,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_conv_math", "sts_set_profiling",
     "sts_get_profile", "sts_set_host_pcm", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
-    "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack",
+    "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack", "sts_debug_set",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
     "sts_multi_create", "sts_multi_destroy", "sts_multi_device_count", "sts_multi_speaker_num", "sts_multi_infer_ids_batch",
     "sts_multi_shard_of", "sts_multi_last_error",
@@ -209,6 +210,10 @@ class Synthesizer:
 
     def set_conv_mode(self, mode: int):
         _check(self.lib, self.lib.sts_set_conv_mode(self.h, mode))
+
+    def debug_set(self, key: str, value: int):
+        """Test hooks (include/summertts_hip.h sts_debug_set): 'attn_block_min_wgs' | 'front_mode'."""
+        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "front_mode": 2}[key], int(value)))
 
     def set_profiling(self, on: bool):
         _check(self.lib, self.lib.sts_set_profiling(self.h, 1 if on else 0))

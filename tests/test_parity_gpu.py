@@ -663,15 +663,15 @@ def test_fused_column_layers_at_every_instantiated_width(width):
 
 
 @pytest.mark.parametrize("kind", ["hifigan_sdp", "ms_hifigan_fix", "mbb_fix"])
-def test_block_attention_kernel_matches_oracle_at_every_size(kind, monkeypatch):
+def test_block_attention_kernel_matches_oracle_at_every_size(kind):
     """attention_mfma_kernel (16 queries per workgroup on the matrix cores) normally engages from ~100 workgroups on; here it is
     forced for tiny models and ragged lengths (partial 16-query blocks, a 1-phoneme utterance, keys past the last 64-key chunk)
     and the text-encoder output is compared with the oracle utterance by utterance."""
-    monkeypatch.setenv("STS_ATTN_MFMA_MIN_WGS", "1")
     cfg = sb.tiny_cfg(kind)
     blob = sb.make_blob(cfg, 23)
     port = pyref.PortModel(blob)
     syn = engine.Synthesizer(blob)
+    syn.debug_set("attn_block_min_wgs", 1)
     syn.set_record_taps(True)
     lens = [70, 16, 1, 33, 129]
     ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate(lens)]

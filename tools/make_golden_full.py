@@ -29,10 +29,14 @@ from summertts_amd import synth_blob as sb    # noqa: E402
 BATCH_LENS = np.random.default_rng(1234).integers(64, 257, size=8).tolist()   # bench.py --ragged, first 8
 
 
-def batch_case(kind, n_check, spk=1):
-    order = sorted(range(len(BATCH_LENS)), key=lambda i: BATCH_LENS[i])
-    return dict(kind=kind, size="full", batch_lens=BATCH_LENS, batch_sids=[(i * 29) % spk for i in range(len(BATCH_LENS))],
-                check_idx=sorted(order[:n_check]))
+def batch_case(kind, n_check, spk=1, batch=8):
+    """batch == 8: the two shortest members carry reference outputs (round 2).  Larger batches (the 32- / 64-utterance launches
+    of BASELINE configs[2]-[4]): the shortest member and the median one."""
+    lens = BATCH_LENS if batch == 8 else np.random.default_rng(1234).integers(64, 257, size=batch).tolist()
+    order = sorted(range(len(lens)), key=lambda i: lens[i])
+    check = order[:n_check] if batch == 8 else [order[0], order[len(order) // 2]][:n_check]
+    return dict(kind=kind, size="full", batch_lens=lens, batch_sids=[(i * 29) % spk for i in range(len(lens))],
+                check_idx=sorted(check))
 
 
 CASES = {
@@ -40,6 +44,11 @@ CASES = {
     "full_mbb_fix_T96": dict(kind="mbb_fix", size="full", utts=[(96, 3, 0, 1.0)]),
     "full_ms_sdp_T96": dict(kind="ms_sdp", size="full", utts=[(96, 4, 0, 1.0)]),
     "full_ms_hifigan_sdp_T64": dict(kind="ms_hifigan_sdp", size="full", utts=[(64, 5, 0, 1.0), (64, 5, 57, 1.0), (64, 5, 173, 1.05)]),
+    # the exact workload of bench.py's headline line (BASELINE configs[1]): hifigan_sdp, ONE utterance, ids = synthetic_ids(128, vocab, salt 0)
+    "full_hifigan_sdp_T128": dict(kind="hifigan_sdp", size="full", utts=[(128, 0, 0, 1.0)]),
+    # the 32- / 64-utterance launches of configs[3] (per-GPU share) and configs[4]
+    "full_batch32_ms_hifigan_sdp": batch_case("ms_hifigan_sdp", 2, spk=174, batch=32),
+    "full_batch64_mbb_fix": batch_case("mbb_fix", 2, batch=64),
     "full_batch8_mbb_fix": batch_case("mbb_fix", 2),
     "full_batch8_hifigan_sdp": batch_case("hifigan_sdp", 2),
     "full_batch8_ms_hifigan_sdp": batch_case("ms_hifigan_sdp", 2, spk=174),

@@ -73,6 +73,30 @@ void run(const char* name, int blocks, int iters) {
     hipFree(d);
 }
 
+// Library form (tools/ubench/Makefile -> libsts_ubench.so): bench.py calls this in its own process so that the bench line carries the
+// ceiling measured on the box and at the moment of the run.  Returns bf16 TFLOP/s (<= 0 on failure).
+extern "C" double sts_ubench_mfma_bf16(int mode, int blocks, int iters) {
+    float* d = nullptr;
+    if (hipMalloc(&d, 4) != hipSuccess) return -1.0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&](int it) {
+        if (mode == 0) hipLaunchKernelGGL((k<0, 4>), dim3(blocks), dim3(256), 0, 0, d, it);
+        else if (mode == 1) hipLaunchKernelGGL((k<1, 4>), dim3(blocks), dim3(256), 0, 0, d, it);
+        else hipLaunchKernelGGL((k<2, 4>), dim3(blocks), dim3(256), 0, 0, d, it);
+    };
+    launch(50);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    launch(iters);
+    hipEventRecord(e1);
+    float ms = 0.f;
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
+    if (!ok) return -1.0;
+    return (double)blocks * 4 * iters * 24 * 2.0 * 32 * 32 * 16 / ms / 1e9;
+}
+
+#ifndef STS_UBENCH_LIB
 int main() {
     run<0, 4>("constant operands, 4 waves/WG, 1 WG/CU", 256, 20000);
     run<0, 4>("constant operands, 4 waves/WG, 2 WG/CU", 512, 20000);
@@ -82,3 +106,4 @@ int main() {
     run<2, 4>("planes of split random fp32 operands, 1 WG/CU", 256, 20000);
     return 0;
 }
+#endif
