@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Power + shader-clock telemetry under the decoder trunk and under the bare-MFMA micro-benchmark.
+
+Samples the GPU's hwmon sensors (sysfs: power1_average / power1_input in uW, freq1_input = sclk in Hz; falls back to
+`rocm-smi --showpower --showclocks --json`) every 50 ms from a helper thread while the main thread keeps the GPU busy for
+~5 s per phase:
+  idle | the synthesis step at batch 1 | at batch 8 (ragged) | tools/ubench/libsts_ubench.so on constant operands, random
+  bf16 operands, and the hi/mid/lo planes of random fp32 data.
+Prints per phase: samples, mean / max power (W), mean / min sclk (MHz), and the phase's own throughput figure.
+  python tools/power_trace.py [seconds_per_phase]"""
+import ctypes
+import glob
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def find_sensors():
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        p = next((os.path.join(hw, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, n))), None)
+        f = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
+        if p:
+            return p, f
+    return None, None
+
+
+class Sampler:
+    def __init__(self, period=0.05):
+        self.period, self.rows, self.stop = period, [], False
+        self.pfile, self.ffile = find_sensors()
+        self.mode = "sysfs" if self.pfile else "rocm-smi"
+
+    def read(self):
+        if self.pfile:
+            try:
+                pw = int(open(self.pfile).read()) / 1e6
+                fq = int(open(self.ffile).read()) / 1e6 if self.ffile else float("nan")
+                return pw, fq
+            except Exception:
+                return float("nan"), float("nan")
+        try:
+            j = json.loads(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout)
+            c = next(iter(j.values()))
+            pw = next((float(v) for k, v in c.items() if "Power" in k and "W" in k), float("nan"))
+            fq = next((float(str(v).strip("()Mhz ")) for k, v in c.items() if k.lower().startswith("sclk")), float("nan"))
+            return pw, fq
+        except Exception:
+            return float("nan"), float("nan")
+
+    def run(self):
+        while not self.stop:
+            t = time.perf_counter()
+            self.rows.append((t,) + self.read())
+            time.sleep(max(0.0, self.period - (time.perf_counter() - t)))
+
+    def phase(self, name, fn, seconds):
+        self.rows, self.stop = [], False
+        th = threading.Thread(target=self.run, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        note = fn(seconds)
+        el = time.perf_counter() - t0
+        self.stop = True
+        th.join()
+        a = np.array([r[1:] for r in self.rows if r[0] - t0 > 0.5] or [(float("nan"), float("nan"))])   # skip the ramp
+        print(f"{name:58s} {el:5.1f} s  {len(a):3d} samples @ {1e3 * self.period:.0f} ms ({self.mode})  power mean {np.nanmean(a[:, 0]):6.1f} W max {np.nanmax(a[:, 0]):6.1f} W"
+              f"   sclk mean {np.nanmean(a[:, 1]):6.0f} MHz min {np.nanmin(a[:, 1]):6.0f} MHz   {note}", flush=True)
+
+
+def main():
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
+    from summertts_amd import engine, synth_blob as sb
+    cfg = sb.full_cfg("hifigan_sdp")
+    blob = sb.make_blob(cfg, 1234)
+    syn = engine.Synthesizer(blob)
+    s = Sampler()
+    cap = ""
+    if s.pfile:
+        for n in ("power1_cap", "power1_cap_default", "power1_cap_max"):
+            f = os.path.join(os.path.dirname(s.pfile), n)
+            if os.path.exists(f):
+                try:
+                    cap += f" {n}={int(open(f).read()) / 1e6:.0f} W"
+                except Exception:
+                    pass
+    print(f"sensors: power={s.pfile} sclk={s.ffile}{cap}", flush=True)
+
+    def idle(sec):
+        time.sleep(sec)
+        return ""
+
+    def synth(batch):
+        lens = [128] if batch == 1 else np.random.default_rng(1234).integers(64, 257, size=batch).tolist()
+        ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=u) for u, t in enumerate(lens)]
+
+        def f(sec):
+            syn.set_profiling(True)
+            t0, n, dec, fl = time.perf_counter(), 0, 0.0, 0.0
+            while time.perf_counter() - t0 < sec:
+                n += int(syn.run_batch(ids).sum())
+                p = syn.profile()
+                dec += p["ms_decoder_mfma"]; fl += p["flops_decoder_mfma"]
+            return f"{n / (time.perf_counter() - t0) / 16000:.0f}x real-time, trunk {fl / dec / 1e9:.0f} TF/s fp32-equivalent"
+        return f
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libsts_ubench.so"))
+    lib.sts_ubench_mfma_bf16.restype = ctypes.c_double
+    lib.sts_ubench_mfma_bf16.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+
+    def ub(mode):
+        def f(sec):
+            t0, r = time.perf_counter(), []
+            while time.perf_counter() - t0 < sec:
+                r.append(lib.sts_ubench_mfma_bf16(mode, 512, 200000))       # ~0.2 s per call
+            return f"{np.mean(r):.0f} bf16 TF/s = {np.mean(r) / 6:.0f} fp32-equivalent"
+        return f
+
+    s.phase("idle", idle, 2.0)
+    s.phase("synthesis step, batch 1 (128 phonemes)", synth(1), secs)
+    s.phase("synthesis step, batch 8 (64..256 phonemes)", synth(8), secs)
+    s.phase("bare MFMA loop, constant operands", ub(0), secs)
+    s.phase("bare MFMA loop, random bf16 operands", ub(1), secs)
+    s.phase("bare MFMA loop, hi/mid/lo planes of random fp32", ub(2), secs)
+    s.phase("idle", idle, 2.0)
+
+
+if __name__ == "__main__":
+    main()
