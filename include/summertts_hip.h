@@ -118,10 +118,10 @@ int sts_set_conv_math(sts_engine* e, int mode);
 
 /*   test hooks (per engine, never read from the environment): force a kernel family that the automatic choice would not pick
  *   at the size of a test.  key: STS_DBG_ATTN_BLOCK_MIN_WGS -- the matrix-core block attention kernel engages from this many
- *   workgroups on (default 96; 1 = always);  STS_DBG_FRONT_MODE -- text encoder + duration predictor + flow at small batch:
- *   0 = automatic (single-XCD persistent kernel where it applies), 1 = always one launch per layer, 2 = persistent kernel
- *   whenever it is eligible, regardless of the batch size. */
-enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2 };
+ *   workgroups on (default 96; 1 = always);  STS_DBG_FRONT_MODE -- the reverse flow of a one-utterance call:
+ *   0 = automatic (today: one launch per layer), 1 = always one launch per layer, 2 = the persistent single-launch kernel of
+ *   persist.hip (one window of the frame axis per XCD) whenever the model is eligible. */
+enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2, STS_DBG_PK_TRACE = 3 /* per-op timeline of the persistent kernel -> tap "pk_trace" */ };
 int sts_debug_set(sts_engine* e, int key, int value);
 
 /* Per-stage device timing of the last run, measured with HIP events on the engine's own stream. */

@@ -31,6 +31,8 @@ Engine::~Engine() {
     if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
     if (hmap_) (void)hipHostFree(hmap_);
     if (arrive_) (void)hipFree(arrive_);
+    if (pk_prog_) (void)hipFree(pk_prog_);
+    if (pk_ctr_) (void)hipFree(pk_ctr_);
     if (have_events_) {
         for (auto& e : ev_) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_fork_);
@@ -252,6 +254,79 @@ float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv,
     return cur;
 }
 
+// The reverse flow as ONE persistent launch (persist.hip): the op list of ResidualCouplingBlock.cpp:59-70 / ResidualCouplingLayer.cpp:47-66 /
+// WN.cpp:100-149 in execution order, every op annotated with the halo its output still needs (the receptive field of all the ops
+// behind it).  Static per model; built and uploaded on first use.
+bool Engine::flow_program() {
+    if (pk_state_) return pk_state_ > 0;
+    pk_state_ = -1;
+    const Model& M = model;
+    if (M.n_flows <= 0 || (M.n_flows & 1)) return false;       // an odd count ends with a channel reversal of z (flip_channels)
+    const int C = M.inter, half = C / 2;
+    auto conv_ok = [](const DConv& c) {
+        return !c.depthwise && !c.transposed && c.Cin >= 32 && c.Cin_pad % 8 == 0 && c.Cout_pad % 32 == 0 && (c.k & 1) &&
+               c.pad == c.dil * (c.k - 1) / 2 && c.wk8 != nullptr && c.Cin % 4 == 0 && c.Cout % 4 == 0;
+    };
+    if ((M.inter / 2) % 4 != 0) return false;
+    std::vector<int> R(M.n_flows, 0);
+    for (int i = 0; i < M.n_flows; i++) {
+        const DCoupling& cp = M.cp[i];
+        const DWn& w = cp.wn;
+        if (!conv_ok(cp.pre) || !conv_ok(cp.post) || cp.pre.k != 1 || cp.post.k != 1 || w.n < 1 || w.H % 16 != 0) return false;
+        if (cp.pre.Cin != half || cp.pre.Cout != w.H || cp.post.Cin != w.H || cp.post.Cout != half) return false;
+        for (int l = 0; l < w.n; l++) {
+            if (!conv_ok(w.in[l]) || !conv_ok(w.rs[l]) || !w.in[l].gate_perm || w.rs[l].k != 1) return false;
+            if (w.in[l].Cin != w.H || w.in[l].Cout != 2 * w.H || w.rs[l].Cin != w.H) return false;
+            if (w.rs[l].Cout != (l + 1 < w.n ? 2 * w.H : w.H)) return false;
+            R[i] += w.in[l].dil * (w.in[l].k - 1) / 2;
+        }
+        if (w.H != M.cp[0].wn.H || w.n != M.cp[0].wn.n) return false;
+    }
+    std::vector<PkStep> P;
+    auto conv_step = [&](const DConv& c, int halo, int epi, int in_buf, int in_row, int out_buf, int out_row) {
+        PkStep s;
+        memset(&s, 0, sizeof(s));
+        s.kind = PK_CONV; s.halo = halo; s.w = c.wk8; s.bias = c.bias; s.ubias_off = -1;
+        s.Cin = c.Cin; s.Cout = c.Cout; s.Cin_pad = c.Cin_pad; s.Cout_pad = c.Cout_pad; s.ntap = c.k; s.tap_step = c.dil; s.tap_off = -c.pad;
+        s.epi = epi; s.H = c.H; s.gate_perm = c.gate_perm;
+        s.in_buf = in_buf; s.in_row = in_row; s.out_buf = out_buf; s.out_row = out_row; s.aux_buf = 3;
+        return s;
+    };
+    int total = 0;
+    for (int r : R) total += r;
+    { PkStep s; memset(&s, 0, sizeof(s)); s.kind = PK_EXPAND; s.halo = total; s.out_buf = 0; s.ubias_off = -1; P.push_back(s); }
+    int Hp = total;                       // halo the NEXT coupling's input half still needs
+    const int wnL = M.cp[0].wn.n, wnH = M.cp[0].wn.H;
+    for (int i = M.n_flows - 1; i >= 0; i--) {
+        const DCoupling& cp = M.cp[i];
+        const DWn& w = cp.wn;
+        Hp -= R[i];                       // halo of this coupling's own output (x1 - m)
+        const int x0row = cp.flipped ? half : 0, dstrow = cp.flipped ? 0 : half;
+        P.push_back(conv_step(cp.pre, Hp + R[i], EPI_STORE, 0, x0row, 1, 0));
+        int a = Hp + R[i];
+        for (int l = 0; l < w.n; l++) {
+            a -= w.in[l].dil * (w.in[l].k - 1) / 2;
+            PkStep g = conv_step(w.in[l], a, EPI_GATE, 1, 0, 2, 0);
+            g.H = w.H;
+            if (w.has_cond) g.ubias_off = i * ((2 * wnH * wnL + 3) & ~3) + l * 2 * w.H;      // 16-byte aligned blocks (cf. run())
+            P.push_back(g);
+            PkStep r = conv_step(w.rs[l], a, EPI_RESSKIP, 2, 0, 1, 0);
+            r.H = w.H; r.epi_flag = l == 0 ? 1 : 0;
+            P.push_back(r);
+        }
+        P.push_back(conv_step(cp.post, Hp, EPI_SUB, 3, 0, 0, dstrow));
+    }
+    { PkStep s; memset(&s, 0, sizeof(s)); s.kind = PK_STORE_OUT; s.halo = 0; s.in_buf = 0; s.ubias_off = -1; P.push_back(s); }
+    if ((int)P.size() > PK_MAX_STEPS || Hp != 0) return false;
+    if (hipMalloc((void**)&pk_prog_, P.size() * sizeof(PkStep)) != hipSuccess) { pk_prog_ = nullptr; return false; }
+    if (hipMalloc((void**)&pk_ctr_, pk_counter_bytes()) != hipSuccess) { pk_ctr_ = nullptr; return false; }
+    if (hipMemcpy(pk_prog_, P.data(), P.size() * sizeof(PkStep), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemset(pk_ctr_, 0, pk_counter_bytes()) != hipSuccess) return false;
+    pk_nsteps_ = (int)P.size(); pk_halo_ = total;
+    pk_state_ = 1;
+    return true;
+}
+
 void Engine::tap(const char* name, const float* d, int channels, long ld, long length) {
     if (!record_taps) return;
     Tap& t = taps[name];
@@ -292,7 +367,7 @@ struct BufT {
     float *g, *cond_dp, *cond_dec, *cond_wn;
 };
 struct BufF {
-    float *z, *h, *acts, *out, *x0, *regA, *regB, *tailA, *tailB, *tailC, *wave, *fliptmp;
+    float *z, *h, *acts, *out, *x0, *regA, *regB, *tailA, *tailB, *tailC, *wave, *fliptmp, *pk; long long* pk_trace;
     int16_t* pcm;
 };
 
@@ -351,7 +426,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         bt.g = A.get<float>((size_t)(M.gin > 0 ? M.gin : 1) * B);
         bt.cond_dp = A.get<float>((size_t)(fdp > H ? fdp : H) * B);
         bt.cond_dec = A.get<float>((size_t)(M.up_init > 0 ? M.up_init : 1) * B);
-        bt.cond_wn = A.get<float>((size_t)(2 * wnH * wnL + 1) * B);
+        bt.cond_wn = A.get<float>((size_t)(2 * wnH * wnL + 4) * B * (M.n_flows > 0 ? M.n_flows : 1));   // one block per coupling
     };
     arenaT_.measuring = true; layoutT(arenaT_);
     if (!ensure(arenaT_, arenaT_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (phoneme-level workspace)");
@@ -590,9 +665,20 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
           if (i & 1) { if (stage_elems[i] > regB) regB = stage_elems[i]; } else { if (stage_elems[i] > regA) regA = stage_elems[i]; } } }
     const long Lsb = Wcap * upS + B;           // MB-iSTFT: frames + 1 per window
     const int sbC = M.conv_post.Cout;
+    // one utterance: the whole flow as ONE persistent launch, the frame axis cut into one window per XCD (persist.hip).  Measured on
+    // MI355X (profiles/r03_pk_flow_trace.log): correct and deadlock-free, but at 128 phonemes it takes 0.50 ms against
+    // 0.44 ms for the 41 launches -- an op inside the persistent kernel still costs ~6 us of dependent latencies (claim, operand
+    // round trips, partial-sum exchange, store acknowledgement, completion poll) and the gate convs are fp32-MFMA-bound on windows
+    // that overlap 1.77x -- so the launch-per-layer path stays the default and this one is opt-in: front_mode 2 (sts_debug_set)
+    const bool use_pk = B == 1 && !M.cp.empty() && front_mode == 2 && conv_mode == 0 && conv_math != 2 && Ftot <= 16384 && flow_program();
+    const int pk_fs = (int)((Ftot + 7) / 8);
+    const int pk_wld = (pk_fs + 2 * pk_halo_ + 31) / 32 * 32 + 32;
+    const int pk_rows = C > wnH ? C : wnH;
     BufF bf;
     auto layoutF = [&](Arena& A) {
         A.used = 0;
+        bf.pk = A.get<float>(use_pk ? (size_t)8 * 4 * pk_rows * pk_wld : 1);
+        bf.pk_trace = A.get<long long>(use_pk && pk_trace ? (size_t)256 * PK_MAX_STEPS * 8 : 1);
         bf.z = A.get<float>((size_t)C * Ftot); bf.h = A.get<float>((size_t)wnH * Ftot);
         bf.acts = A.get<float>((size_t)wnH * Ftot); bf.out = A.get<float>((size_t)wnH * Ftot);
         bf.fliptmp = A.get<float>((M.n_flows & 1) ? (size_t)C * Ftot : 1);
@@ -614,11 +700,61 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     mark(7);
     // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
     stage_begin(2);
+    const int half = C / 2;
+    if (use_pk) {
+        if (record_taps) { expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream); tap("z_p", bf.z, C, Ftot, Ftot); }
+        const long cstride = (long)((2 * wnH * wnL + 3) & ~3);
+        for (int i = M.n_flows - 1; i >= 0; i--) {        // speaker conditioning of every coupling up front + the stage's FLOP / byte account
+            const DCoupling& cp = M.cp[i];
+            const DWn& w = cp.wn;
+            if (w.has_cond) conv(w.cond, bt.g, lvB, bt.cond_wn + (size_t)i * cstride, lvB, ConvOpt());
+            (void)conv_args(cp.pre, nullptr, lv1, nullptr, lv1, ConvOpt(), nullptr);
+            for (int l = 0; l < w.n; l++) {
+                ConvOpt og; og.epi = EPI_GATE;
+                (void)conv_args(w.in[l], nullptr, lv1, nullptr, lv1, og, nullptr);
+                ConvOpt orr; orr.epi = EPI_RESSKIP;
+                (void)conv_args(w.rs[l], nullptr, lv1, nullptr, lv1, orr, nullptr);
+            }
+            ConvOpt os; os.epi = EPI_SUB;
+            (void)conv_args(cp.post, nullptr, lv1, nullptr, lv1, os, nullptr);
+        }
+        PkFlowArgs P;
+        memset(&P, 0, sizeof(P));
+        P.prog = pk_prog_; P.nsteps = pk_nsteps_;
+        P.m = bt.m; P.m_ld = Ttot; P.cum = bt.cum; P.T = (int)Ttot;
+        P.z = bf.z; P.z_ld = Ftot; P.F = (int)Ftot; P.C = C;
+        P.priv = bf.pk; P.priv_stride = (long)4 * pk_rows * pk_wld; P.wld = pk_wld; P.rows = pk_rows;
+        P.fs = pk_fs; P.halo_total = pk_halo_;
+        P.cond = bt.cond_wn; P.ctr = pk_ctr_;
+        if (pk_trace) { (void)hipMemsetAsync(bf.pk_trace, 0, (size_t)256 * PK_MAX_STEPS * 8 * sizeof(long long), stream); P.trace = bf.pk_trace; }
+        pk_flow(P, stream);
+        if (pk_trace) {     // debugging aid: [256][PK_MAX_STEPS][4] ticks relative to the earliest stamp, as floats
+            std::vector<long long> h((size_t)256 * PK_MAX_STEPS * 8);
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h.data(), bf.pk_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            // every XCD has its own counter: stamps are made relative to the earliest stamp of the workgroup's XCD
+            long long t0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            std::vector<int> xcd(256, -1);
+            for (int wg = 0; wg < 256; wg++)
+                for (int s2 = 0; s2 < PK_MAX_STEPS && xcd[wg] < 0; s2++) { const long long v = h[((size_t)wg * PK_MAX_STEPS + s2) * 8 + 3]; if (v > 0) xcd[wg] = (int)(v / 1000) & 7; }
+            for (int wg = 0; wg < 256; wg++) if (xcd[wg] >= 0)
+                for (int s2 = 0; s2 < PK_MAX_STEPS; s2++) for (int q = 0; q < 8; q++) {
+                    const long long v = h[((size_t)wg * PK_MAX_STEPS + s2) * 8 + q];
+                    if (q != 3 && v && (!t0[xcd[wg]] || v < t0[xcd[wg]])) t0[xcd[wg]] = v;
+                }
+            Tap& t = taps["pk_trace"];
+            t.channels = 256 * 8; t.length = PK_MAX_STEPS;
+            t.data.assign((size_t)256 * 8 * PK_MAX_STEPS, -1.f);
+            for (int wg = 0; wg < 256; wg++) if (xcd[wg] >= 0) for (int s2 = 0; s2 < PK_MAX_STEPS; s2++) for (int q = 0; q < 8; q++) {
+                const long long v = h[((size_t)wg * PK_MAX_STEPS + s2) * 8 + q];
+                t.data[((size_t)wg * 8 + q) * PK_MAX_STEPS + s2] = q == 3 ? (float)v : (v ? (float)(v - t0[xcd[wg]]) : -1.f);
+            }
+        }
+    } else {
     expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream);
     tap("z_p", bf.z, C, Ftot, Ftot);
 
     // ---------------- reverse flow (ResidualCouplingBlock.cpp:59-70, ResidualCouplingLayer.cpp:47-66, WN.cpp:100-149)
-    const int half = C / 2;
     for (int i = M.n_flows - 1; i >= 0; i--) {
         const DCoupling& cp = M.cp[i];
         const float* x0 = bf.z + (size_t)(cp.flipped ? half : 0) * Ftot;
@@ -636,6 +772,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         }
         ConvOpt os; os.epi = EPI_SUB; os.tile = flow_1x1_tile;
         conv(cp.post, bf.out, lv1, dst, lv1, os);
+    }
     }
     if (M.n_flows & 1) flip_channels(bf.z, Ftot, C, Ftot, bf.fliptmp, stream);
     tap("z", bf.z, C, Ftot, Ftot);

@@ -71,6 +71,7 @@ public:
     int conv_mode = 0;
     int conv_math = 0;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA (sts_set_conv_math)
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
+    bool pk_trace = false;             // record the persistent kernel's per-op timeline into taps["pk_trace"] (sts_debug_set)
     int front_mode = 0;                // 0 automatic, 1 one launch per layer, 2 persistent single-XCD kernel wherever eligible (sts_debug_set)
     hipStream_t stream = nullptr;
 
@@ -84,6 +85,7 @@ private:
     int pick_kslices(const DConv& c, const Lvl& lout) const;
     float* dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre = nullptr, const float* pre_in = nullptr,
                const float* pre_res = nullptr);
+    bool flow_program();            // builds (once) the op program of the persistent single-launch flow (persist.hip); false: not eligible
     void tap(const char* name, const float* d, int channels, long ld, long length);
     void stage_begin(int s);
     void mark(int i);
@@ -94,6 +96,7 @@ private:
     char* pinned_pcm_ = nullptr; size_t pinned_pcm_cap_ = 0;
     int* hmap_ = nullptr; int* hmap_dev_ = nullptr; size_t hmap_cap_ = 0;   // host-mapped result block of the durations kernel
     unsigned* arrive_ = nullptr; int seq_ = 0;
+    PkStep* pk_prog_ = nullptr; int pk_nsteps_ = 0, pk_halo_ = 0, pk_state_ = 0; unsigned* pk_ctr_ = nullptr;   // persistent flow kernel
     hipEvent_t ev_[8] = {};
     static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently
     hipStream_t aux_[kAux] = {};

@@ -135,6 +135,32 @@ struct AttnArgs {
     int block_min_wgs;              // the 16-queries-per-workgroup matrix-core kernel from this many workgroups on (0: default 96)
 };
 
+// ---- persistent single-launch flow (persist.hip): the reverse flow of ONE utterance, frame axis cut into 8 windows (one per XCD),
+// every window processed by the workgroups of its XCD with L2-local barriers between the ops
+constexpr int PK_MAX_STEPS = 96;
+enum PkKind : int { PK_EXPAND = 0, PK_CONV = 1, PK_STORE_OUT = 2 };
+struct PkStep {
+    int kind;
+    int halo;                       // the op's output is needed on the frames an XCD owns +- halo
+    const float* w; const float* bias;      // packed weights [ntap][Cin_pad][Cout_pad] / bias [Cout_pad] (model storage)
+    int ubias_off;                  // per-utterance bias (speaker conditioning): float offset into PkFlowArgs::cond, < 0: none
+    int Cin, Cout, Cin_pad, Cout_pad, ntap, tap_step, tap_off;
+    int epi, epi_flag, H, gate_perm;
+    int in_buf, in_row, out_buf, out_row, aux_buf;      // private buffers 0..3 (z, h, acts, out) and first row inside them
+};
+struct PkFlowArgs {
+    const PkStep* prog; int nsteps;
+    const float* m; long m_ld; const int* cum; int T;   // length regulator source: m [C][m_ld], cum[T] = inclusive prefix of the durations
+    float* z; long z_ld; int F; int C;                  // shared output z [C][z_ld], F frames
+    float* priv; long priv_stride; int wld, rows;       // per XCD: 4 buffers of [rows][wld] floats, priv_stride floats apart
+    int fs, halo_total;                                 // frames owned per XCD, receptive field of the whole flow (per side)
+    const float* cond;                                  // base of the per-utterance biases
+    unsigned* ctr;                                      // pk_counter_bytes() of zeroed device memory (re-armed by the kernel itself)
+    long long* trace;                                   // optional [256 workgroups][PK_MAX_STEPS][8]: s_memtime at op start / chunk done / op complete, xcd * 1000 + chunk + 1, conv entry / K loop done / partials combined / stores complete
+};
+size_t pk_counter_bytes();
+void pk_flow(const PkFlowArgs& A, hipStream_t st);
+
 // ---- launchers (all asynchronous on `st`) ------------------------------------------------------
 // Matrix-core (v_mfma_f32_32x32x2_f32) implicit-GEMM conv.  Returns false when the shape is not
 // eligible (caller then uses conv_generic).  `tile` < 0 picks a tile configuration heuristically.

@@ -33,6 +33,7 @@ struct DConv {
     const float* wc = nullptr;      // col_layer / col_proj A-strip copy of a 1x1 conv (DDSConv pointwise convs, attention o-proj, q/k/v, encoder proj)
     const float* bias_rows = nullptr;   // bias in source row order next to wc (== bias where the conv's rows are not permuted)
     const float* wu = nullptr;      // Winograd-domain copy [seg][4][Cin_pad][Cout_pad] (narrow decoder ResBlock convs)
+    const float* wk8 = nullptr;     // [tap][Cin_pad / 8][Cout_pad][8] copy for the persistent flow kernel (persist.hip)
     const void* wb3 = nullptr;      // split-bf16 copy (conv_bf3.hip: three bf16 planes, fragment order) of the decoder trunk convs
     const void* wb3p = nullptr;     // the same with the k order of resblock_bf3_kernel's parked intermediate (second conv of a narrow ResBlock layer)
     double macs_per_out = 0;   // true-tap MACs per output position (all output channels)

@@ -687,3 +687,58 @@ def test_block_attention_kernel_matches_oracle_at_every_size(kind):
         assert_pcm_close(pcm[soff:soff + o["pcm"].size], o["pcm"], f"{kind} utterance {i}")
         soff += o["pcm"].size
     syn.close()
+
+
+@pytest.mark.parametrize("kind", ["hifigan_sdp", "ms_hifigan_sdp", "mbb_fix", "ms_sdp"])
+def test_persistent_flow_kernel_matches_the_per_layer_launches(kind):
+    """persist.hip: the reverse flow of one utterance as ONE launch (frame axis cut into one window per XCD, halo = the receptive
+    field of the remaining ops, L2-local barriers) against the launch-per-layer path: the latent z, durations and PCM, for
+    lengths from a single frame-window up to more frames than 8 windows' halos, twice (the counters re-arm themselves)."""
+    cfg = sb.tiny_cfg(kind)
+    blob = sb.make_blob(cfg, 77)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    for T in (1, 2, 3, 7, 19, 40, 97, 260):
+        ids = sb.synthetic_ids(T, cfg.vocab, salt=T)
+        sid = [T % syn.get_speaker_num()]
+        got = {}
+        for mode in (1, 2, 2):
+            syn.debug_set("front_mode", mode)
+            syn.run_batch([ids], sid)
+            got.setdefault(mode, []).append((syn.tap("z").copy(), syn.tap("z_p").copy(), syn.pcm_host().copy(), syn.durations(T).copy()))
+        z1, zp1, pcm1, d1 = got[1][0]
+        for z2, zp2, pcm2, d2 in got[2]:
+            assert np.array_equal(d1, d2) and np.array_equal(zp1, zp2)
+            assert z1.shape == z2.shape and np.abs(z1 - z2).max() <= TAP_MAXABS_TOL, (kind, T, np.abs(z1 - z2).max())
+            assert_pcm_close(pcm2, pcm1, f"{kind} T={T}: persistent flow vs launches")
+        assert np.array_equal(got[2][0][0], got[2][1][0]) and np.array_equal(got[2][0][2], got[2][1][2]), "persistent flow is not deterministic"
+    syn.close()
+
+
+def test_persistent_flow_kernel_at_full_size_and_beyond_its_default_range():
+    """Full-size model: the bench's own 128-phoneme utterance and a 420-phoneme one (~2 200 frames) under the persistent flow
+    kernel (opt-in: front_mode 2) against the launch-per-layer path; the odd-coupling-count and narrow-channel models must
+    fall back to launches and still run."""
+    cfg = sb.full_cfg("hifigan_sdp")
+    blob = sb.make_blob(cfg, 1234)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    for T in (128, 420):
+        ids = sb.synthetic_ids(T, cfg.vocab, salt=0)
+        out = {}
+        for mode in (1, 2):
+            syn.debug_set("front_mode", mode)
+            syn.run_batch([ids])
+            out[mode] = (syn.tap("z").copy(), syn.pcm_host().copy(), syn.tap("wave")[0].copy())
+        assert np.abs(out[1][0] - out[2][0]).max() <= TAP_MAXABS_TOL, (T, np.abs(out[1][0] - out[2][0]).max())
+        assert_pcm_close(out[2][1], out[1][1], f"full size T={T}")
+        assert_wave_close(out[2][2], out[1][2], f"full size T={T}")
+    syn.close()
+    cfg = sb.tiny_cfg("odd")
+    blob = sb.make_blob(cfg, 5)
+    ids = sb.synthetic_ids(9, cfg.vocab)
+    o = pyref.PortModel(blob).infer_ids(ids, 0, 1.0)
+    syn = engine.Synthesizer(blob)
+    syn.debug_set("front_mode", 2)
+    assert_pcm_close(syn.infer_ids(ids, 0, 1.0), o["pcm"], "odd model with the persistent flow requested")
+    syn.close()
