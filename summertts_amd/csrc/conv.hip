@@ -57,15 +57,17 @@ template <int MW, int NW, int WM, int WN, int RA = 3>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN, NTHR = WM * WN * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int orig_len = seg_len(a.in_seg, b);
+    const int orig_len = uni(seg_len(a.in_seg, b));
     const int in_len = orig_len + (a.in_reflect ? 1 : 0);
-    const int out_len = seg_len(a.out_seg, b);
+    const int out_len = uni(seg_len(a.out_seg, b));
     const int n_count = a.transposed ? in_len + a.n_extra : out_len;
     const int n0 = bx * NT;
     if (n0 >= n_count) return;
     const int phase = by / mtiles;
     const int m0 = (by - phase * mtiles) * MT;
-    const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
+    const size_t in_base = (size_t)uni(seg_start(a.in_seg, b)), out_base = (size_t)uni(seg_start(a.out_seg, b));
+    const float* const xbase = uni(a.x);
+    const long x_ld = uni(a.x_ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
@@ -143,7 +145,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int mtil
 #pragma unroll
                 for (int r = 0; r < CK; r++) {
                     const int ci = c * CK + r;
-                    const rsrc_t rs = make_rsrc(a.x + (size_t)ci * a.x_ld + in_base, ci < a.Cin ? (unsigned)orig_len * 4u : 0u);
+                    const rsrc_t rs = make_rsrc(xbase + (size_t)ci * x_ld + in_base, ci < a.Cin ? (unsigned)orig_len * 4u : 0u);
                     xr[r][i] = buf_load(rs, xoff[i]);   // raw: activation is applied at store time
                 }
             }

@@ -83,14 +83,16 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     constexpr int SPW = (NITEM + NWAVE - 1) / NWAVE;   // items per wave
     constexpr int PLANE = WIN * 32, SUB = 3 * PLANE, BUF = NSUB * SUB;   // bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    const int in_len = seg_len(a.in_seg, b);
-    const int out_len = seg_len(a.out_seg, b);
+    const int in_len = uni(seg_len(a.in_seg, b));
+    const int out_len = uni(seg_len(a.out_seg, b));
     const int n_count = a.transposed ? in_len + a.n_extra : out_len;
     const int n0 = bx * NT;
     if (n0 >= n_count) return;
     const int phase0 = pm ? 0 : by / mtiles;
     const int m0 = pm ? by * MT : (by - phase0 * mtiles) * MT;
-    const size_t in_base = (size_t)seg_start(a.in_seg, b), out_base = (size_t)seg_start(a.out_seg, b);
+    const size_t in_base = (size_t)uni(seg_start(a.in_seg, b)), out_base = (size_t)uni(seg_start(a.out_seg, b));
+    const float* const xbase = uni(a.x);
+    const long x_ld = uni(a.x_ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int kg = swave / NTW;                                    // scalar
@@ -176,7 +178,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 #pragma unroll
         for (int i = 0; i < SPW; i++)
             if (sact[i]) {
-                const rsrc_t rs = make_rsrc(a.x + (size_t)(c * NSUB + isub[i]) * CK * a.x_ld + in_base, (unsigned)((15ul * a.x_ld + in_len) * 4ul));
+                const rsrc_t rs = make_rsrc(xbase + (size_t)(c * NSUB + isub[i]) * CK * x_ld + in_base, (unsigned)((15ul * x_ld + in_len) * 4ul));
 #pragma unroll
                 for (int e = 0; e < 8; e++)
                     xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)xoff[i], (int)((unsigned)e * ld4), 0));

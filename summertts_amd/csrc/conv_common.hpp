@@ -34,6 +34,17 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned byte_off) {
 }
 constexpr unsigned kOOB = 0x7FFFFFF0u;   // byte offset that is out of range for every descriptor
 
+// Wave-uniform values the compiler cannot always prove uniform (a segment table entry fetched with a vector load, a field of a
+// group member selected through a pointer): forcing them into scalar registers keeps buffer descriptors and scalar offsets out of
+// "waterfall" loops (a v_readfirstlane / compare / exec-mask loop around EVERY buffer load; round 3 found 65 of them in the
+// grouped split-bf16 kernels).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long uni(long v) {
+    return (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)v >> 32)) << 32) |
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+template <typename T> __device__ __forceinline__ T* uni(T* p) { return (T*)uni((long)p); }
+
 __device__ __forceinline__ int seg_start(const SegView& s, int b) { return (s.off ? s.off[b] : s.ioff) * s.scale + b * s.extra; }
 __device__ __forceinline__ int seg_len(const SegView& s, int b) { return (s.off ? s.len[b] : s.ilen) * s.scale + s.extra; }
 
