@@ -39,6 +39,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef STS_EXP
 #define STS_EXP 0   // timing experiments only (tools/exp_build.sh); 0 in every shipped build
 #endif
+// A/B switches of round 3's instruction-count work on the staged kernel (tools/var_build.sh builds one library per mask; every
+// mask computes identical results).  Measured on MI355X at one utterance (profiles/r03_bf3_variants.log; box-to-box spread ~3 %):
+//   1  no scheduling barrier in front of a step's MFMAs ............... +0.3 % (slower)
+//   2  leaky relu as max(v, slope v) (2 instead of 4 VALU per staged value) \ together -1.4 % of the trunk: kept (default 6)
+//   4  plain tiles: step index == position in the packed weights ......... /
+//   8  a step's LDS reads / weight loads interleaved with its MFMAs (sched_group_barrier) ... no effect
+//   16 weight fragments requested two steps ahead (ring of 3, 214 VGPRs) .................... no effect
+// i.e. the kernel is bound neither by instruction issue in the staging / bookkeeping code nor by weight latency.
+#ifndef STS_VAR
+#define STS_VAR 6
+#endif
 
 // exact three-way split of 8 fp32 values (one lane's 8 channels) into bf16 planes; element e of a plane sits in the low
 // (e even) / high (e odd) half of dword e / 2 -- the order v_mfma_*_bf16 reads its 8 k values in
@@ -171,6 +182,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     }
     float xr[SPW][8];
     int as = 0;        // next A step to request
+    const float act_slope = a.in_act ? a.in_slope : 1.0f;
     auto load_x = [&](int c) {
         if ((STS_EXP & 1) && c > 0) return;
         // one descriptor per 16-channel sub-chunk, based at its first row: rows ride in the scalar offset, the per-lane
@@ -191,8 +203,15 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         for (int i = 0; i < SPW; i++)
             if (sact[i]) {
                 float v[8];
+                if (STS_VAR & 2) {
+                    // leaky relu (0 <= slope <= 1) as max(v, slope v): two instructions per value instead of compare + multiply + two selects
+                    // (no activation: slope 1).  v < 0: slope v >= v; v >= 0: v >= slope v; -0 / +0 as the select form gives them
 #pragma unroll
-                for (int e = 0; e < 8; e++) { v[e] = xr[i][e]; if (a.in_act) v[e] = v[e] < 0.f ? v[e] * a.in_slope : v[e]; }
+                    for (int e = 0; e < 8; e++) v[e] = __builtin_fmaxf(xr[i][e], xr[i][e] * act_slope);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { v[e] = xr[i][e]; if (a.in_act) v[e] = v[e] < 0.f ? v[e] * a.in_slope : v[e]; }
+                }
                 u32x4 ph, pm, pl;
                 split8(v, ph, pm, pl);
                 *(u32x4*)(sb + lds_w[i]) = ph;
@@ -202,20 +221,29 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     };
 
     // ---- main loop over this wave's steps (chunk, sub-chunk, tap): A (L2) and B (LDS) fragments one step ahead
-    u32x4 fa[2][MW][3], fb[2][NW][3];
+    // A ring: 2 = the fragments of step s + 1 are requested during step s; 3 (STS_VAR & 16, plain tiles only) = two steps ahead
+    constexpr int AR = ((STS_VAR & 16) && NSUB == 1 && KG == 1) ? 3 : 2;
+    u32x4 fa[AR][MW][3], fb[2][NW][3];
     int sj = 0, ssub = kg, sc = 0;
     auto a_index = [&](int c, int sub, int j) { return (c * NSUB + sub) * a.ntap + j; };
     auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
         int nj = sj + 1, nsub = ssub, nc = sc;
+        if ((STS_VAR & (4 | 16)) && NSUB == 1 && KG == 1) {
+            // one sub-chunk, one wave group: the step index IS the position in the packed weights, only (tap, chunk) are tracked
+            if (nj == a.ntap) { nj = 0; nc = sc + 1; }
+            nsub = 0;
+            if (!(STS_EXP & 2) || s < 2) load_a(s + AR - 1, anew);
+        } else {
         if (nj == a.ntap) { nj = 0; nsub = ssub + KG; if (nsub >= NSUB) { nsub = kg; nc = sc + 1; } }
         if (!(STS_EXP & 2) || s < 2) load_a(a_index(nc, nsub, nj), anew);   // unconditional: past the last step it reads 0 beyond the descriptor, never used
+        }
         if (nc != sc && s + 1 < nsteps) {
             store_tile(nc & 1);           // chunk nc's tile (in registers since the start of chunk sc)
             if (!(STS_EXP & 4)) __syncthreads();              // tile nc visible; everyone is done reading the buffer it replaces
             if (nc + 1 < nchunk) load_x(nc + 1);
         }
         if (!(STS_EXP & 16) || s < 2) load_b(nc & 1, nsub, nj, bnxt);   // past the last step: stale LDS inside the tile, never used
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(STS_VAR & 1)) __builtin_amdgcn_sched_barrier(0);
         if (!(STS_EXP & 64))
 #pragma unroll
         for (int p = 0; p < 6; p++)
@@ -223,18 +251,28 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             for (int i = 0; i < MW; i++)
 #pragma unroll
                 for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(acur[i][kProdA[p]], bcur[q][kProdB[p]], acc[i][q]);
+        if (STS_VAR & 8) {
+            // the step's 6 LDS reads and 6 weight loads spread between its MFMAs (2 MFMAs per memory operation)
+#pragma unroll
+            for (int r = 0; r < 6 * MW * NW / 2; r++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+            }
+        }
         sj = nj; ssub = nsub; sc = nc;
     };
     load_x(0);
     load_a(a_index(0, kg, 0), fa[0]);
+    if constexpr (AR == 3) load_a(1, fa[1]);
     store_tile(0);
     __syncthreads();
     load_b(0, kg, 0, fb[0]);
     if (nchunk > 1) load_x(1);
-    for (int s = 0; s < nsteps; s += 2)
-        static_for<0, 2>([&](auto uc) {
+    for (int s = 0; s < nsteps; s += 2 * AR)
+        static_for<0, 2 * AR>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            if (s + u < nsteps) do_step(fa[u % 2], fa[(u + 1) % 2], fb[u % 2], fb[(u + 1) % 2], s + u);
+            if (u < 2 || s + u < nsteps) { if (s + u < nsteps) do_step(fa[u % AR], fa[(u + AR - 1) % AR], fb[u % 2], fb[(u + 1) % 2], s + u); }
         });
 
     if constexpr (KG > 1) {
