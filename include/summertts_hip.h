@@ -187,6 +187,17 @@ const char* sts_pool_last_error(void);
  * The handle is not re-entrant (one batch at a time), like an engine. */
 typedef struct sts_multi sts_multi;
 int sts_multi_create(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, sts_multi** out);
+/*   How the PCM comes home.  STS_MULTI_AUTO (= sts_multi_create): the RCCL gather when the devices are distinct and more than
+ *   one, the per-device PCIe download otherwise (or when librccl cannot be loaded).  STS_MULTI_RCCL: one RCCL communicator rank
+ *   per device (ncclCommInitAll; distinct devices required, one is allowed): sample counts by ncclAllGather, the int16 PCM of
+ *   ranks > 0 by ncclSend / grouped ncclRecv into a gather buffer on devices[0] (over xGMI), then ONE download.
+ *   STS_MULTI_DOWNLOAD: every device downloads its own shard.  sts_multi_gather_mode reports which one a handle uses (1 = RCCL). */
+enum { STS_MULTI_AUTO = 0, STS_MULTI_RCCL = 1, STS_MULTI_DOWNLOAD = 2 };
+int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, int32_t flags, sts_multi** out);
+int sts_multi_gather_mode(const sts_multi* m);
+/*   layout of the gather buffer (host arithmetic only): rank r's block starts at offsets[r] samples (256-byte aligned);
+ *   returns the buffer's extent in samples */
+int64_t sts_multi_gather_layout(const int64_t* counts, int32_t n_ranks, int64_t* offsets);
 void sts_multi_destroy(sts_multi* m);
 int sts_multi_device_count(const sts_multi* m);
 int sts_multi_speaker_num(const sts_multi* m);

@@ -7,10 +7,23 @@
 // count (the same rule as summertts_amd/sharding.py: work is ~proportional to it), every device runs its shard as ONE
 // packed variable-length batch on its own worker thread, downloads its int16 PCM through its own pinned staging buffer,
 // and the caller gets the utterances back in INPUT order.  The result lives on the host (malloc'd per utterance, like
-// sts_infer_ids_batch), so the "gather" is the per-device PCIe download -- there is nothing to move between GPUs; the
-// RCCL gather of summertts_amd/sharding.py is for the one-process-per-GPU deployment, where rank 0 owns the output.
+// sts_infer_ids_batch).
+//
+// Two ways of bringing the PCM home (sts_multi_gather_mode):
+//   * RCCL gather (round 3; the xGMI path BASELINE.json's north_star names): when the listed devices are all distinct (and more than
+//     one, or STS_MULTI_RCCL is asked for), the handle owns one RCCL communicator per device (ncclCommInitAll).  After its shard
+//     has run, every worker publishes its sample count with ncclAllGather, ranks > 0 ncclSend their int16 PCM straight out of the
+//     engine's device buffer, rank 0 posts the matching ncclRecvs (one group) into a gather buffer on device 0 laid out by
+//     sts_multi_gather_layout, adds its own shard device-to-device, and ONE device-to-host copy brings the whole batch down.
+//     librccl is dlopen'ed on first use: a process that never asks for the gather never loads it.
+//   * per-device download: each worker downloads its own shard over PCIe (devices that repeat in the list, single device).
+// N > 1 with RCCL has not been measured (no multi-GPU node was available to the builder): the code path is exercised on one GPU
+// with a one-rank communicator (tests/test_parity_gpu.py) and its layout arithmetic on the CPU (tests/test_abi_cpu.py).
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -27,6 +40,33 @@
 using namespace sts;
 
 namespace {
+// ---- librccl, resolved at run time
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load() {
+        if (h) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        AllGather = (decltype(AllGather))sym("ncclAllGather"); Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        return CommInitAll && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
+std::mutex g_rccl_mu;
+
 struct Shard {
     std::vector<int> utt;              // indices into the caller's batch, ascending
     std::vector<int16_t> pcm;          // packed PCM of the shard (utterance order of `utt`)
@@ -44,6 +84,60 @@ struct sts_multi {
     int64_t epoch = 0; int pending = 0; bool stop = false;
     int32_t B = 0; const int32_t* const* ids = nullptr; const int32_t* n = nullptr; const int32_t* sid = nullptr; const float* ls = nullptr;
     std::vector<Shard> shards;
+    // RCCL gather state (gather_mode == 1)
+    int gather_mode = 0;
+    std::vector<ncclComm_t> comms;
+    std::vector<long long*> d_counts;       // per device: [1 own count | ndev gathered counts]
+    int16_t* d_gather = nullptr; size_t gather_cap = 0;      // on engines[0]'s device
+    int16_t* h_gather = nullptr; size_t h_gather_cap = 0;    // pinned
+    std::vector<int64_t> counts, offsets; int64_t gather_total = 0;
+
+    // after the shard has run: counts -> all ranks, PCM of ranks > 0 -> rank 0 over xGMI, rank 0 downloads everything at once
+    void rccl_gather(int k) {
+        Shard& sh = shards[k];
+        Engine& eng = *engines[k];
+        Rccl& R = rccl();
+        const int nd = (int)engines.size();
+        const long long mine = sh.rc == STS_OK && !sh.utt.empty() ? (long long)eng.total_samples : 0;    // a failed shard still takes part
+        auto ck = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess && sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + R.GetErrorString(r); } return r == ncclSuccess; };
+        auto hk = [&](hipError_t e, const char* what) { if (e != hipSuccess && sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + hipGetErrorString(e); } return e == hipSuccess; };
+        long long host_counts[65];
+        hk(hipMemcpyAsync(d_counts[k], &mine, sizeof(long long), hipMemcpyHostToDevice, eng.stream), "count upload");
+        ck(R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, comms[k], eng.stream), "ncclAllGather");
+        hk(hipMemcpyAsync(host_counts, d_counts[k] + 1, sizeof(long long) * nd, hipMemcpyDeviceToHost, eng.stream), "count download");
+        hk(hipStreamSynchronize(eng.stream), "count sync");
+        if (k > 0) {
+            if (mine > 0) ck(R.Send(eng.d_pcm, (size_t)mine, ncclHalf, 0, comms[k], eng.stream), "ncclSend");
+            hk(hipStreamSynchronize(eng.stream), "send sync");       // the engine's PCM buffer is free again
+            return;
+        }
+        // rank 0: layout, receive, own shard, one download
+        counts.assign(host_counts, host_counts + nd);
+        offsets.resize(nd);
+        gather_total = sts_multi_gather_layout(counts.data(), nd, offsets.data());
+        const size_t need = (size_t)std::max<int64_t>(gather_total, 1);
+        if (need > gather_cap) {
+            if (d_gather) (void)hipFree(d_gather);
+            d_gather = nullptr; gather_cap = 0;
+            if (hk(hipMalloc((void**)&d_gather, (need + need / 4) * 2), "gather buffer")) gather_cap = need + need / 4;
+        }
+        if (need > h_gather_cap) {
+            if (h_gather) (void)hipHostFree(h_gather);
+            h_gather = nullptr; h_gather_cap = 0;
+            if (hk(hipHostMalloc((void**)&h_gather, (need + need / 4) * 2, hipHostMallocDefault), "pinned gather buffer")) h_gather_cap = need + need / 4;
+        }
+        // the receives are posted even after a local failure (into a scratch-sized buffer they would not fit: then fail the job but
+        // keep the peers from hanging is impossible -- so allocation failure above is fatal for the process' job, reported)
+        if (d_gather && gather_cap >= need) {
+            ck(R.GroupStart(), "ncclGroupStart");
+            for (int p = 1; p < nd; p++)
+                if (counts[p] > 0) ck(R.Recv(d_gather + offsets[p], (size_t)counts[p], ncclHalf, p, comms[0], eng.stream), "ncclRecv");
+            ck(R.GroupEnd(), "ncclGroupEnd");
+            if (mine > 0) hk(hipMemcpyAsync(d_gather + offsets[0], eng.d_pcm, (size_t)mine * 2, hipMemcpyDeviceToDevice, eng.stream), "own shard");
+            if (h_gather) hk(hipMemcpyAsync(h_gather, d_gather, (size_t)gather_total * 2, hipMemcpyDeviceToHost, eng.stream), "gather download");
+        }
+        hk(hipStreamSynchronize(eng.stream), "gather sync");
+    }
 
     void worker(int k) {
         Engine& eng = *engines[k];
@@ -62,7 +156,9 @@ struct sts_multi {
                 std::vector<const int32_t*> idp(nb); std::vector<int32_t> nn(nb), sd(nb); std::vector<float> l(nb);
                 for (int i = 0; i < nb; i++) { const int u = sh.utt[i]; idp[i] = ids[u]; nn[i] = n[u]; sd[i] = sid ? sid[u] : 0; l[i] = ls ? ls[u] : 1.0f; }
                 sh.rc = eng.run(nb, idp.data(), nn.data(), sd.data(), l.data());
-                if (sh.rc == STS_OK) {
+                if (sh.rc == STS_OK && gather_mode == 1) {
+                    sh.n_samples = eng.n_samples;           // the PCM stays on the device: rccl_gather() below
+                } else if (sh.rc == STS_OK) {
                     sh.n_samples = eng.n_samples;
                     sh.pcm.resize((size_t)std::max<int64_t>(1, eng.total_samples));
                     if (eng.h_pcm) memcpy(sh.pcm.data(), eng.h_pcm, (size_t)eng.total_samples * 2);   // downloaded inside the run
@@ -72,6 +168,7 @@ struct sts_multi {
                     sh.err = eng.error();
                 }
             }
+            if (gather_mode == 1) rccl_gather(k);       // every rank takes part, also with an empty or failed shard
             {
                 std::lock_guard<std::mutex> lk(mu);
                 pending--;
@@ -105,19 +202,66 @@ extern "C" {
 
 const char* sts_multi_last_error(void) { return g_multi_err.c_str(); }
 
+// block of rank r starts at offsets[r] (in samples, 128-sample = 256-byte aligned so that every transfer starts on a cache-line
+// pair); returns the total extent.  Host arithmetic only.
+int64_t sts_multi_gather_layout(const int64_t* counts, int32_t n_ranks, int64_t* offsets) {
+    int64_t off = 0;
+    for (int r = 0; r < n_ranks; r++) {
+        if (offsets) offsets[r] = off;
+        const int64_t c = counts && counts[r] > 0 ? counts[r] : 0;
+        off += (c + 127) / 128 * 128;
+    }
+    return off;
+}
+
+int sts_multi_gather_mode(const sts_multi* m) { return m ? m->gather_mode : 0; }
+
 int sts_multi_create(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, sts_multi** out) {
+    return sts_multi_create_ex(blob, blob_bytes, devices, n_devices, STS_MULTI_AUTO, out);
+}
+
+int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, int32_t flags, sts_multi** out) {
     if (!out) return multi_err(STS_EINVAL, "null out pointer");
     *out = nullptr;
     if (!devices || n_devices < 1 || n_devices > 64) return multi_err(STS_EINVAL, "device list must hold 1..64 entries");
+    if (flags != STS_MULTI_AUTO && flags != STS_MULTI_RCCL && flags != STS_MULTI_DOWNLOAD) return multi_err(STS_EINVAL, "unknown flags");
+    bool distinct = true;
+    for (int a = 0; a < n_devices; a++) for (int b = a + 1; b < n_devices; b++) if (devices[a] == devices[b]) distinct = false;
+    if (flags == STS_MULTI_RCCL && !distinct) return multi_err(STS_EINVAL, "the RCCL gather needs distinct devices (one communicator rank per GPU)");
+    const bool want_rccl = flags == STS_MULTI_RCCL || (flags == STS_MULTI_AUTO && distinct && n_devices >= 2);
     sts_multi* m = new (std::nothrow) sts_multi();
     if (!m) return multi_err(STS_EDEVICE, "out of host memory");
     for (int k = 0; k < n_devices; k++) {
         m->engines.emplace_back(new Engine());
-        m->engines.back()->host_pcm = true;
+        m->engines.back()->host_pcm = !want_rccl;
         const int rc = m->engines.back()->init(blob, blob_bytes, devices[k]);
         if (rc != STS_OK) { multi_err(rc, "device " + std::to_string(devices[k]) + ": " + m->engines.back()->error()); delete m; return rc; }
     }
     m->shards.resize(n_devices);
+    if (want_rccl) {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        Rccl& R = rccl();
+        if (!R.load()) {
+            if (flags == STS_MULTI_RCCL) { multi_err(STS_EDEVICE, R.err); delete m; return STS_EDEVICE; }
+            for (auto& e : m->engines) e->host_pcm = true;                      // automatic mode: fall back to per-device downloads
+        } else {
+            m->comms.resize(n_devices);
+            std::vector<int> devs(devices, devices + n_devices);
+            const ncclResult_t r = R.CommInitAll(m->comms.data(), n_devices, devs.data());
+            if (r != ncclSuccess) {
+                m->comms.clear();
+                if (flags == STS_MULTI_RCCL) { multi_err(STS_EDEVICE, std::string("ncclCommInitAll: ") + R.GetErrorString(r)); delete m; return STS_EDEVICE; }
+                for (auto& e : m->engines) e->host_pcm = true;
+            } else {
+                m->gather_mode = 1;
+                m->d_counts.assign(n_devices, nullptr);
+                for (int k = 0; k < n_devices; k++) {
+                    (void)hipSetDevice(devices[k]);
+                    if (hipMalloc((void**)&m->d_counts[k], sizeof(long long) * (n_devices + 1)) != hipSuccess) { multi_err(STS_EDEVICE, "count buffer"); sts_multi_destroy(m); return STS_EDEVICE; }
+                }
+            }
+        }
+    }
     for (int k = 0; k < n_devices; k++) m->workers.emplace_back([m, k] { m->worker(k); });
     *out = m;
     return STS_OK;
@@ -128,6 +272,10 @@ void sts_multi_destroy(sts_multi* m) {
     { std::lock_guard<std::mutex> lk(m->mu); m->stop = true; }
     m->cv_go.notify_all();
     for (auto& t : m->workers) t.join();
+    for (size_t k = 0; k < m->comms.size(); k++) if (m->comms[k]) (void)rccl().CommDestroy(m->comms[k]);
+    for (size_t k = 0; k < m->d_counts.size(); k++) if (m->d_counts[k]) { (void)hipSetDevice(m->engines[k]->device); (void)hipFree(m->d_counts[k]); }
+    if (m->d_gather) { (void)hipSetDevice(m->engines[0]->device); (void)hipFree(m->d_gather); }
+    if (m->h_gather) (void)hipHostFree(m->h_gather);
     delete m;
 }
 
@@ -165,15 +313,26 @@ int sts_multi_infer_ids_batch(sts_multi* m, int32_t B, const int32_t* const* ids
     int rc = STS_OK;
     for (int k = 0; k < ndev && rc == STS_OK; k++)
         if (m->shards[k].rc != STS_OK) rc = multi_err(m->shards[k].rc, "device slot " + std::to_string(k) + ": " + m->shards[k].err);
+    if (rc == STS_OK && m->gather_mode == 1) {
+        // the counts every rank published must be the ones the engines reported on the host
+        for (int k = 0; k < ndev && rc == STS_OK; k++) {
+            int64_t want = 0;
+            for (int32_t v : m->shards[k].n_samples) want += v;
+            if (m->shards[k].utt.empty()) want = 0;
+            if ((int)m->counts.size() != ndev || m->counts[k] != want) rc = multi_err(STS_EDEVICE, "RCCL gather: sample counts disagree");
+        }
+        if (rc == STS_OK && !m->h_gather && m->gather_total > 0) rc = multi_err(STS_EDEVICE, "RCCL gather: no host buffer");
+    }
     for (int k = 0; k < ndev && rc == STS_OK; k++) {
         const Shard& sh = m->shards[k];
         size_t off = 0;
+        const int16_t* src = m->gather_mode == 1 ? m->h_gather + m->offsets[k] : sh.pcm.data();
         for (size_t i = 0; i < sh.utt.size() && rc == STS_OK; i++) {
             const int u = sh.utt[i];
             const int32_t ns = sh.n_samples[i];
             pcm_out[u] = (int16_t*)malloc((size_t)(ns > 0 ? ns : 1) * 2);
             if (!pcm_out[u]) { rc = multi_err(STS_EDEVICE, "out of host memory"); break; }
-            memcpy(pcm_out[u], sh.pcm.data() + off, (size_t)ns * 2);
+            memcpy(pcm_out[u], src + off, (size_t)ns * 2);
             n_out[u] = ns;
             off += (size_t)ns;
         }

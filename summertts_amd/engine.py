@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_set_forced_durations",
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_conv_math", "sts_set_profiling",
     "sts_get_profile", "sts_set_host_pcm", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_free", "sts_last_error",
-    "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack", "sts_debug_set",
+    "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack", "sts_debug_set", "sts_multi_create_ex", "sts_multi_gather_mode", "sts_multi_gather_layout",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
     "sts_multi_create", "sts_multi_destroy", "sts_multi_device_count", "sts_multi_speaker_num", "sts_multi_infer_ids_batch",
     "sts_multi_shard_of", "sts_multi_last_error",
@@ -336,10 +336,25 @@ class Pool:
             pass
 
 
+def multi_gather_layout(counts: Sequence[int]):
+    """Host arithmetic of the RCCL gather buffer (sts_multi_gather_layout): -> (offsets per rank, extent), in samples."""
+    lib = load_library()
+    lib.sts_multi_gather_layout.restype = C.c_int64
+    lib.sts_multi_gather_layout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    c = np.ascontiguousarray(counts, dtype=np.int64)
+    off = np.zeros(c.size, np.int64)
+    total = int(lib.sts_multi_gather_layout(c.ctypes.data, c.size, off.ctypes.data))
+    return off, total
+
+
 class MultiDevice:
     """``sts_multi``: one process, one engine per listed HIP device; batches are sharded by utterance."""
 
-    def __init__(self, blob: np.ndarray, devices: Sequence[int]):
+    MODES = {"auto": 0, "rccl": 1, "download": 2}
+
+    def __init__(self, blob: np.ndarray, devices: Sequence[int], gather: str = "auto"):
+        """gather: 'auto' (RCCL gather to devices[0] when the devices are distinct and more than one) | 'rccl' (force it, also for
+        one device) | 'download' (every device downloads its own shard)."""
         self.lib = load_library()
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         dev = np.ascontiguousarray(devices, dtype=np.int32)
@@ -352,9 +367,14 @@ class MultiDevice:
         self.lib.sts_multi_infer_ids_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_void_p, C.c_void_p]
         self.lib.sts_multi_shard_of.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
-        rc = self.lib.sts_multi_create(blob.ctypes.data, blob.nbytes, dev.ctypes.data, dev.size, C.byref(self.h))
+        self.lib.sts_multi_create_ex.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        self.lib.sts_multi_gather_mode.argtypes = [C.c_void_p]
+        rc = self.lib.sts_multi_create_ex(blob.ctypes.data, blob.nbytes, dev.ctypes.data, dev.size, self.MODES[gather], C.byref(self.h))
         if rc != 0:
-            raise StsError(f"sts_multi_create: {rc}: {self.lib.sts_multi_last_error().decode()}")
+            raise StsError(f"sts_multi_create_ex: {rc}: {self.lib.sts_multi_last_error().decode()}")
+
+    def gather_mode(self) -> str:
+        return "rccl" if int(self.lib.sts_multi_gather_mode(self.h)) == 1 else "download"
 
     def device_count(self) -> int:
         return int(self.lib.sts_multi_device_count(self.h))

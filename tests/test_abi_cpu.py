@@ -113,3 +113,20 @@ def test_winograd_weight_transform_reproduces_the_direct_conv(k, dil):
     got[:, n] = M[0] + M[1] + M[2]
     got[:, n + dil] = M[1] - M[2] - M[3]
     assert np.abs(got - direct).max() < 1e-5
+
+
+def test_multi_device_gather_layout_and_flag_validation(lib):
+    """Host logic of the native RCCL gather (multi.hip): every rank's block of the gather buffer starts 256-byte aligned, empty
+    ranks take no room, blocks do not overlap; and the argument checks that run before any device is touched."""
+    off, total = engine.multi_gather_layout([171008, 0, 5, 128, 129])
+    assert off.tolist() == [0, 171008, 171008, 171136, 171264] and total == 171264 + 256
+    assert all(int(o) % 128 == 0 for o in off)
+    off, total = engine.multi_gather_layout([0, 0])
+    assert off.tolist() == [0, 0] and total == 0
+    blob = np.zeros(64, np.float32)
+    with pytest.raises(engine.StsError, match="distinct devices"):
+        engine.MultiDevice(blob, [0, 0], gather="rccl")
+    lib.sts_multi_create_ex.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    h = C.c_void_p()
+    dev = np.zeros(1, np.int32)
+    assert lib.sts_multi_create_ex(blob.ctypes.data, blob.nbytes, dev.ctypes.data, 1, 7, C.byref(h)) < 0      # unknown flags

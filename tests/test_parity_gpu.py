@@ -742,3 +742,34 @@ def test_persistent_flow_kernel_at_full_size_and_beyond_its_default_range():
     syn.debug_set("front_mode", 2)
     assert_pcm_close(syn.infer_ids(ids, 0, 1.0), o["pcm"], "odd model with the persistent flow requested")
     syn.close()
+
+
+def test_multi_device_rccl_gather_with_a_one_rank_communicator():
+    """The native RCCL path of sts_multi (ncclCommInitAll, counts by ncclAllGather, gather buffer on device 0, ONE download) on what a
+    one-GPU box allows: a single-rank communicator.  Same PCM as the per-device download and as a plain engine; the automatic
+    mode with a repeated device falls back to downloads."""
+    cfg = sb.tiny_cfg("hifigan_sdp")
+    blob = sb.make_blob(cfg, 11)
+    lens = [9, 33, 5, 21]
+    ids = [sb.synthetic_ids(t, cfg.vocab, salt=i) for i, t in enumerate(lens)]
+    syn = engine.Synthesizer(blob)
+    want = [syn.infer_ids(a, 0, 1.0) for a in ids]
+    syn.close()
+    md = engine.MultiDevice(blob, [0], gather="rccl")
+    assert md.gather_mode() == "rccl"
+    for _ in range(2):                      # twice: buffers and communicator are reused
+        got = md.infer_batch(ids)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert_pcm_close(g, w, f"RCCL gather, utterance {i}")      # (a packed batch may pick other tiles than a single call)
+    md.close()
+    md = engine.MultiDevice(blob, [0, 0])
+    assert md.gather_mode() == "download"
+    got2 = md.infer_batch(ids)
+    md.close()
+    md = engine.MultiDevice(blob, [0], gather="download")
+    got1 = md.infer_batch(ids)
+    md.close()
+    for i, (g, w) in enumerate(zip(got2, want)):
+        assert_pcm_close(g, w, f"download, utterance {i}")
+    for g, w in zip(got, got1):
+        assert np.array_equal(g, w)          # same shard, same engine path: the gather itself must not change a sample
