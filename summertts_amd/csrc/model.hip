@@ -50,12 +50,79 @@ HLn parse_ln(Reader& r) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // packed weight store: one device allocation, one upload
+// Packed-weight store.  Kernel-ready pointers are handed out WHILE the blob is parsed, so the device base address must exist before
+// the final size is known.  Where the virtual-memory API works (probed; ADVICE r02: a 3x-blob hipMalloc kept ~370 MB per engine
+// for a 112 MB model, and its heuristic bound could overflow on a valid model), only ADDRESS SPACE is reserved up front --
+// generously: 8x the blob + 64 MB -- and physical memory of exactly the used size is mapped behind it after packing; otherwise a
+// plain hipMalloc of the bound.  The host mirror is calloc'ed (untouched pages cost nothing).
+struct HostArena {
+    float* p = nullptr;
+    float* data() const { return p; }
+};
 struct Store {
-    std::vector<float> host; float* dev = nullptr; size_t cap = 0, used = 0;
-    bool init(size_t capacity) {
-        cap = capacity;
-        host.assign(cap, 0.f);
+    HostArena host; float* dev = nullptr; size_t cap = 0, used = 0;
+    bool vmm = false; size_t gran = 0, reserved = 0;
+    hipMemGenericAllocationHandle_t handle{}; size_t mapped = 0;
+    ~Store() { free(host.p); }
+    static bool vmm_probe(int device, size_t* gran_out) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        size_t g = 0;
+        if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || g == 0) { (void)hipGetLastError(); return false; }
+        void* va = nullptr; hipMemGenericAllocationHandle_t h{};
+        bool ok = hipMemAddressReserve(&va, 2 * g, 0, nullptr, 0) == hipSuccess;
+        if (ok) {
+            ok = hipMemCreate(&h, g, &prop, 0) == hipSuccess;
+            if (ok) {
+                ok = hipMemMap(va, g, 0, h, 0) == hipSuccess;
+                if (ok) {
+                    hipMemAccessDesc ad = {}; ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+                    ok = hipMemSetAccess(va, g, &ad, 1) == hipSuccess && hipMemset(va, 0, 256) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                    (void)hipMemUnmap(va, g);
+                }
+                (void)hipMemRelease(h);
+            }
+            (void)hipMemAddressFree(va, 2 * g);
+        }
+        if (!ok) (void)hipGetLastError();
+        *gran_out = g;
+        return ok;
+    }
+    bool init(size_t blob_floats) {
+        int device = 0;
+        (void)hipGetDevice(&device);
+        vmm = vmm_probe(device, &gran);
+        cap = vmm ? blob_floats * 8 + (16u << 20) : blob_floats * 4 + (8u << 20);
+        host.p = (float*)calloc(cap, sizeof(float));
+        if (!host.p) return false;
+        if (vmm) {
+            reserved = (cap * sizeof(float) + gran - 1) / gran * gran;
+            void* va = nullptr;
+            if (hipMemAddressReserve(&va, reserved, 0, nullptr, 0) == hipSuccess) { dev = (float*)va; return true; }
+            (void)hipGetLastError();
+            vmm = false; cap = blob_floats * 4 + (8u << 20);
+        }
         return hipMalloc((void**)&dev, cap * sizeof(float)) == hipSuccess;
+    }
+    // physical memory behind the used part of the reservation (VMM) -- then the caller uploads `used` floats
+    bool commit() {
+        if (!vmm) return true;
+        int device = 0;
+        (void)hipGetDevice(&device);
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        mapped = (used * sizeof(float) + 4096 + gran - 1) / gran * gran;       // + slack: unconditional prefetches read a little past the end
+        if (hipMemCreate(&handle, mapped, &prop, 0) != hipSuccess) return false;
+        if (hipMemMap(dev, mapped, 0, handle, 0) != hipSuccess) { (void)hipMemRelease(handle); return false; }
+        hipMemAccessDesc ad = {}; ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(dev, mapped, &ad, 1) != hipSuccess) { (void)hipMemUnmap(dev, mapped); (void)hipMemRelease(handle); return false; }
+        return hipMemset(dev, 0, mapped) == hipSuccess;
+    }
+    void release_device() {       // on a failed load
+        if (!dev) return;
+        if (vmm) { if (mapped) { (void)hipMemUnmap(dev, mapped); (void)hipMemRelease(handle); } (void)hipMemAddressFree(dev, reserved); }
+        else (void)hipFree(dev);
+        dev = nullptr;
     }
     // returns host pointer to fill and the matching device pointer
     float* alloc(size_t n, const float** dptr) {
@@ -285,8 +352,8 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
     Reader r{blob, nfloats};
     Store st;
     // repacking pads channel counts to 16/32 and transposed convs to whole phases: bound generously
-    if (!st.init((size_t)nfloats * 4 + (32u << 20))) FAIL("hipMalloc of the weight store failed");
-    m.dev_weights = st.dev;
+    if (!st.init((size_t)nfloats)) FAIL("allocation of the weight store failed");
+    m.dev_weights = st.dev; m.dev_vmm = st.vmm; m.dev_reserved = st.reserved;
 
     // header: /root/reference/src/models/SynthesizerTrn.cpp:103-106
     m.is_ms = r.geti(); m.lang = r.geti(); m.dur_type = r.geti(); m.dec_type = r.geti();
@@ -476,13 +543,20 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
     m.consumed = r.o;
     { const float* slack; if (!st.alloc(1024, &slack)) FAIL("weight store overflow"); }   // kernels may read one row tile past a tensor
     m.dev_floats = st.used;
+    if (!st.commit()) FAIL("mapping device memory behind the weight store failed");
+    m.dev_mapped = st.mapped; m.dev_handle = st.vmm ? (void*)st.handle : nullptr;
     if (hipMemcpy(st.dev, st.host.data(), st.used * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) FAIL("weight upload failed");
     return true;
 }
 
 void free_model(Model& m) {
-    if (m.dev_weights) (void)hipFree(m.dev_weights);
-    m.dev_weights = nullptr;
+    if (m.dev_weights) {
+        if (m.dev_vmm) {
+            if (m.dev_mapped) { (void)hipMemUnmap(m.dev_weights, m.dev_mapped); (void)hipMemRelease((hipMemGenericAllocationHandle_t)m.dev_handle); }
+            (void)hipMemAddressFree(m.dev_weights, m.dev_reserved);
+        } else (void)hipFree(m.dev_weights);
+    }
+    m.dev_weights = nullptr; m.dev_mapped = 0;
 }
 
 }  // namespace sts

@@ -80,6 +80,7 @@ struct Model {
     const float* emb_g = nullptr;
     // device storage
     float* dev_weights = nullptr; size_t dev_floats = 0;
+    bool dev_vmm = false; size_t dev_reserved = 0, dev_mapped = 0; void* dev_handle = nullptr;   // virtual-memory form of the store (model.hip Store)
     int64_t consumed = 0;
     std::string error;
 };
