@@ -51,6 +51,29 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define STS_VAR 6
 #endif
 
+#ifdef STS_TILE_TRACE
+// Lab build only (tools/var_build.sh with -DSTS_TILE_TRACE): every workgroup of the staged kernel appends one record
+// {gridDim.x, blockIdx.x, xcc | hw id, realtime at start, s_memtime at start / first barrier / K loop done / epilogue done}
+__device__ long long* g_tile_trace = nullptr;
+__device__ unsigned g_tile_trace_cap = 0;
+__device__ unsigned g_tile_trace_n = 0;
+extern "C" int sts_debug_tile_trace(long long* buf, unsigned capacity_records) {
+    unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace), &buf, sizeof(buf)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_cap), &capacity_records, sizeof(unsigned)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_n), &zero, sizeof(unsigned)) != hipSuccess) return -1;
+    return 0;
+}
+extern "C" int sts_debug_tile_trace_count() {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tile_trace_n), sizeof(unsigned)) != hipSuccess) return -1;
+    return (int)n;
+}
+#define TT_STAMP(i) do { if (tt_rec && threadIdx.x == 0) tt_rec[4 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TT_STAMP(i) do { } while (0)
+#endif
+
 // exact three-way split of 8 fp32 values (one lane's 8 channels) into bf16 planes; element e of a plane sits in the low
 // (e even) / high (e odd) half of dword e / 2 -- the order v_mfma_*_bf16 reads its 8 k values in
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
@@ -94,6 +117,19 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     constexpr int SPW = (NITEM + NWAVE - 1) / NWAVE;   // items per wave
     constexpr int PLANE = WIN * 32, SUB = 3 * PLANE, BUF = NSUB * SUB;   // bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+#ifdef STS_TILE_TRACE
+    long long* tt_rec = nullptr;
+    if (g_tile_trace && threadIdx.x == 0) {
+        const unsigned slot = atomicAdd(&g_tile_trace_n, 1u);
+        if (slot < g_tile_trace_cap) {
+            tt_rec = g_tile_trace + (size_t)slot * 8;
+            tt_rec[0] = (long long)gridDim.x; tt_rec[1] = (long long)blockIdx.x;
+            tt_rec[2] = (long long)((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf) << 16 | (__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) & 0xffff));
+            tt_rec[3] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+    }
+    TT_STAMP(0);
+#endif
     const int in_len = uni(seg_len(a.in_seg, b));
     const int out_len = uni(seg_len(a.out_seg, b));
     const int n_count = a.transposed ? in_len + a.n_extra : out_len;
@@ -267,6 +303,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     if constexpr (AR == 3) load_a(1, fa[1]);
     store_tile(0);
     __syncthreads();
+    TT_STAMP(1);
     load_b(0, kg, 0, fb[0]);
     if (nchunk > 1) load_x(1);
     for (int s = 0; s < nsteps; s += 2 * AR)
@@ -314,7 +351,12 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         return;
     }
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
+    TT_STAMP(2);
     if (wvalid) tile_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
+#ifdef STS_TILE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores have left
+    TT_STAMP(3);
+#endif
 }
 
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
@@ -548,32 +590,48 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                 }
             });
     }
-    // ---- epilogue: + b2 + x (the residual is re-read: the staged copy was activated and split); a row tile's 16 bias values
-    // and a column tile's 16 residual values are requested together and waited for once
-    static_for<0, MW>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        float b2v[16];
+    // ---- epilogue: + b2 + x (the residual is re-read: the staged copy was activated and split).  As in tile_epilogue
+    // (conv_common.hpp): a 4 x 4 transpose inside the lane quads turns a lane's 4 consecutive rows of one column into 4 consecutive
+    // columns of one row, so the tile's residual arrives and its result leaves through 16-byte accesses (a quarter of the memory
+    // instructions; the epilogue was store-issue-bound)
+    {
+        const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            int rowv[4]; float b2v[4];
 #pragma unroll
-        for (int r = 0; r < 16; r++) b2v[r] = 0.f;
-        if (a.b2) {
+            for (int g = 0; g < 4; g++) { rowv[g] = mbase + i * 32 + 8 * g + 4 * half + lane4; b2v[g] = a.b2 ? a.b2[rowv[g]] : 0.f; }
+            static_for<0, NW>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int col = wn * NW * 32 + q * 32 + m4;
+                const int pos = n0 + col;
+                const bool any = col < NT && pos < len, full = col + 3 < NT && pos + 3 < len;
+                f32x4u xv[4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) b2v[r] = a.b2[mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-        }
-        static_for<0, NW>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            const int col = wn * NW * 32 + q * 32 + l31;
-            const int pos = n0 + col;
-            if (col < NT && pos < len) {
-                const size_t opos = base + (size_t)pos;
-                float xv[16];
+                for (int g = 0; g < 4; g++) {
+                    xv[g] = f32x4u{0.f, 0.f, 0.f, 0.f};
+                    if (any) {
+                        const float* xp = a.x + (size_t)rowv[g] * G.ld + base + pos;
+                        if (full) xv[g] = *(const f32x4u*)xp;
+                        else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) xv[g][e] = xp[e]; }
+                    }
+                }
 #pragma unroll
-                for (int r = 0; r < 16; r++) xv[r] = a.x[(size_t)(mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * G.ld + opos];
+                for (int g = 0; g < 4; g++) {
+                    float w[4] = {acc[i][q][4 * g], acc[i][q][4 * g + 1], acc[i][q][4 * g + 2], acc[i][q][4 * g + 3]};
+                    quad_transpose(w, l31);
+                    if (any) {
+                        f32x4u o;
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                    a.y[(size_t)(mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * G.ld + opos] = acc[i][q][r] + b2v[r] + xv[r];
-            }
+                        for (int e = 0; e < 4; e++) o[e] = w[e] + b2v[g] + xv[g][e];
+                        float* yp = a.y + (size_t)rowv[g] * G.ld + base + pos;
+                        if (full) *(f32x4u*)yp = o;
+                        else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) yp[e] = o[e]; }
+                    }
+                }
+            });
         });
-    });
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,7 +677,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 // tile codes: t = 0..5 below with 16-channel chunks, 8 + t the same tile with 32-channel chunks (NSUB = 2)
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
-constexpr int kNumBf3Tiles = 6;
+constexpr int kNumBf3Tiles = 8;      // 6 / 7 (round 3): a wave owns 32 rows x 128 columns -- no two waves of a workgroup fetch the same weight rows
 static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 20 && tile < 25); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
@@ -711,6 +769,10 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
         case 3: launch_bf3<2, 2, 1, 2, 1>(a, nphase, st); break;
         case 4: launch_bf3<1, 2, 1, 4, 1>(a, nphase, st); break;
         case 5: launch_bf3<1, 2, 1, 2, 1>(a, nphase, st); break;
+        case 6: launch_bf3<1, 4, 4, 1, 1>(a, nphase, st); break;      // 128 x 128, four waves of 32 x 128
+        case 7: launch_bf3<1, 4, 2, 1, 1>(a, nphase, st); break;      //  64 x 128, two waves of 32 x 128
+        case 14: launch_bf3<1, 4, 4, 1, 2>(a, nphase, st); break;
+        case 15: launch_bf3<1, 4, 2, 1, 2>(a, nphase, st); break;
         case 8: launch_bf3<2, 2, 2, 2, 2>(a, nphase, st); break;
         case 9: launch_bf3<2, 2, 1, 4, 2>(a, nphase, st); break;
         case 10: launch_bf3<2, 2, 2, 4, 2>(a, nphase, st); break;
@@ -752,6 +814,10 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
         case 3: launch_bf3_group<2, 2, 1, 2, 1>(G, st); break;
         case 4: launch_bf3_group<1, 2, 1, 4, 1>(G, st); break;
         case 5: launch_bf3_group<1, 2, 1, 2, 1>(G, st); break;
+        case 6: launch_bf3_group<1, 4, 4, 1, 1>(G, st); break;
+        case 7: launch_bf3_group<1, 4, 2, 1, 1>(G, st); break;
+        case 14: launch_bf3_group<1, 4, 4, 1, 2>(G, st); break;
+        case 15: launch_bf3_group<1, 4, 2, 1, 2>(G, st); break;
         case 8: launch_bf3_group<2, 2, 2, 2, 2>(G, st); break;
         case 9: launch_bf3_group<2, 2, 1, 4, 2>(G, st); break;
         case 10: launch_bf3_group<2, 2, 2, 4, 2>(G, st); break;

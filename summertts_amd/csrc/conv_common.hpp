@@ -95,6 +95,20 @@ __device__ __forceinline__ void epi_scalar(const ConvArgs& a, int row, size_t op
     }
 }
 
+// 4 x 4 transpose inside every quad of lanes: before, lane 4m + c holds v[j] = M[row j][column 4m + c]; after, it holds
+// v[j] = M[row c][column 4m + j] -- four CONSECUTIVE columns of one row.  Two exchange stages (lane bit 1, then lane bit 0) of
+// DPP quad permutes + selects: ~16 VALU per 4 registers.  All 64 lanes must be active.
+__device__ __forceinline__ float dpp_quad_2301(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_quad_1032(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)); }
+__device__ __forceinline__ void quad_transpose(float (&v)[4], const int lane) {
+    const bool hi = (lane & 2) != 0, lo = (lane & 1) != 0;
+    const float r0 = dpp_quad_2301(hi ? v[0] : v[2]), r1 = dpp_quad_2301(hi ? v[1] : v[3]);
+    if (hi) { v[0] = r0; v[1] = r1; } else { v[2] = r0; v[3] = r1; }
+    const float s0 = dpp_quad_1032(lo ? v[0] : v[1]), s1 = dpp_quad_1032(lo ? v[2] : v[3]);
+    if (lo) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+}
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access with dword alignment (packed rows start anywhere)
+
 // Epilogue on the accumulator registers (C/D layout of every 32x32 MFMA: col (time) = lane & 31,
 // row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)).  The plain and the residual form -- every decoder trunk conv --
 // take a branch-free path: a row tile's 16 bias values and a column tile's 16 residual values are requested together
@@ -104,6 +118,60 @@ template <int MW, int NW>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[MW][NW], const int mbase, const int ncol0, const int l31,
                                              const int half, const int n_count, const int out_len, const size_t out_base, const int phase, const int b) {
     const int out_off = a.out_off + phase;
+    if ((a.epi == EPI_STORE || a.epi == EPI_RESADD) && a.out_stride == 1 && out_off == 0) {
+        // Plain convs (every ResBlock conv of the trunk).  Round 3 (tools/tile_trace.py): with one dword store and one dword residual
+        // load per accumulator register the epilogue of a 128 x 128 tile took 16-24 us -- store-ISSUE-bound, 25-45 % of a tile's
+        // life.  A lane's 4 registers of a row group are 4 consecutive ROWS of one column; after a 4 x 4 transpose inside the lane
+        // quads they are 4 consecutive COLUMNS of one row, so a tile leaves through 16-byte stores (and its residual arrives through
+        // 16-byte loads): a quarter of the memory instructions, each covering four 128-byte row segments.  Same arithmetic per value.
+        const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const bool rows_ok = mbase + i * 32 < a.Cout_pad;
+            float bv[4], uv[4];
+            int rowv[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                rowv[g] = mbase + i * 32 + 8 * g + 4 * half + lane4;
+                bv[g] = (rows_ok && a.bias) ? a.bias[rowv[g]] : 0.f;             // bias is padded to Cout_pad
+                uv[g] = (rows_ok && a.ubias && rowv[g] < a.Cout) ? a.ubias[(size_t)rowv[g] * a.ubias_ld + b] : 0.f;
+            }
+            static_for<0, NW>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int n = ncol0 + q * 32 + m4;
+                const bool full = n + 3 < n_count && n + 3 < out_len;
+                f32x4u rv[4];
+                if (a.epi == EPI_RESADD) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        rv[g] = f32x4u{0.f, 0.f, 0.f, 0.f};
+                        if (rows_ok && rowv[g] < a.Cout && n < n_count) {
+                            const float* rp = a.res + (size_t)rowv[g] * a.res_ld + out_base + n;
+                            if (full) rv[g] = *(const f32x4u*)rp;
+                            else { for (int e = 0; e < 4; e++) if (n + e < n_count && n + e < out_len) rv[g][e] = rp[e]; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float w[4] = {acc[i][q][4 * g], acc[i][q][4 * g + 1], acc[i][q][4 * g + 2], acc[i][q][4 * g + 3]};
+                    quad_transpose(w, l31);
+                    if (rows_ok && rowv[g] < a.Cout && n < n_count) {
+                        f32x4u o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float r = a.epi == EPI_RESADD ? rv[g][e] : 0.f;
+                            o[e] = a.ubias ? ((w[e] + bv[g]) + uv[g]) + r : (w[e] + bv[g]) + r;
+                        }
+                        float* yp = a.y + (size_t)rowv[g] * a.y_ld + out_base + n;
+                        if (full) *(f32x4u*)yp = o;
+                        else { for (int e = 0; e < 4; e++) if (n + e < n_count && n + e < out_len) yp[e] = o[e]; }
+                    }
+                }
+            });
+        });
+        return;
+    }
     if (a.epi == EPI_STORE || a.epi == EPI_RESADD) {
         static_for<0, MW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;

@@ -87,7 +87,7 @@ def test_bf3_conv_is_as_accurate_as_the_fp32_matrix_core_kernel(case):
     y32 = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=2 + 4)          # exact-fp32 MFMA kernel, 32 x 128 tile
     e32 = np.sqrt(np.mean((y32 - ref) ** 2))
     outs = []
-    for mode in (13, 20, 21, 22, 23, 24, 25, 28, 29, 30, 31, 32, 33, 41, 42, 43):   # 41-43: phase-merged rows for transposed convs
+    for mode in (13, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 41, 42, 43):   # 41-43: phase-merged rows for transposed convs
         y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=mode)
         assert y.shape == ref.shape
         err = np.abs(y - ref)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Phase timeline of the staged split-bf16 conv kernel inside a real synthesis step (lab build: tools/var_build.sh with
+VAR_EXTRA=-DSTS_TILE_TRACE).  Every workgroup records s_memtime at start / first barrier (prologue done) / K loop done /
+epilogue stores complete, plus the chip-wide 100 MHz real-time counter at its start.  Prints, per launch (grouped by grid size
+and start time): workgroups, the phases' mean / p90 durations, the launch's span, and how many workgroups started within the
+first 2 us (co-resident wave) -- i.e. how much of a tile's life is not the K loop, and whether the tiles run in lockstep.
+  VAR_EXTRA=-DSTS_TILE_TRACE tools/var_build.sh 6 && SUMMERTTS_HIP_LIB=summertts_amd/lib/var/libvar6.so python tools/tile_trace.py [batch]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from summertts_amd import engine, synth_blob as sb   # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+TICK = float(os.environ.get("TT_TICK_NS", "0.45"))
+cfg = sb.full_cfg("hifigan_sdp")
+blob = sb.make_blob(cfg, 1234)
+syn = engine.Synthesizer(blob)
+lens = [128] if B == 1 else np.random.default_rng(1234).integers(64, 257, size=B).tolist()
+ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=u) for u, t in enumerate(lens)]
+for _ in range(3):
+    syn.run_batch(ids)
+lib = syn.lib
+cap = 1 << 17
+buf = torch.zeros(cap * 8, dtype=torch.int64, device="cuda")
+lib.sts_debug_tile_trace.argtypes = [C.c_void_p, C.c_uint]
+assert lib.sts_debug_tile_trace(buf.data_ptr(), cap) == 0
+syn.run_batch(ids)
+torch.cuda.synchronize()
+n = lib.sts_debug_tile_trace_count()
+lib.sts_debug_tile_trace(None, 0)
+r = buf.cpu().numpy().reshape(-1, 8)[:min(n, cap)]
+print(f"{n} workgroup records, batch {B}; s_memtime tick assumed {TICK} ns (shader clock), real-time tick 10 ns")
+order = np.argsort(r[:, 3], kind="stable")
+r = r[order]
+# launches: runs of equal grid size in start-time order
+launches, cur = [], [0]
+for i in range(1, len(r)):
+    if r[i, 0] != r[cur[0], 0] or (r[i, 3] - r[cur[-1], 3]) * 10e-3 > 30.0:
+        launches.append(cur); cur = [i]
+    else:
+        cur.append(i)
+launches.append(cur)
+print(" launch  grid_wgs  recorded  span_us | prologue mean/p90 | K loop mean/p90 | epilogue mean/p90 | non-K share | started in first 2 us")
+for li, idx in enumerate(launches):
+    q = r[idx]
+    pro = (q[:, 5] - q[:, 4]) * TICK / 1e3; kl = (q[:, 6] - q[:, 5]) * TICK / 1e3; ep = (q[:, 7] - q[:, 6]) * TICK / 1e3
+    ok = (q[:, 7] > 0) & (q[:, 6] > 0)
+    if not ok.any():
+        continue
+    t0 = (q[:, 3] - q[:, 3].min()) * 10e-3
+    end = t0 + (q[:, 7] - q[:, 4]) * TICK / 1e3
+    first = int((t0 < 2.0).sum())
+    print(f"{li:7d} {int(q[0, 0]) // 256:9d} {len(idx):9d} {end[ok].max():8.1f} | {pro[ok].mean():7.2f} {np.percentile(pro[ok], 90):6.2f} | {kl[ok].mean():7.2f} {np.percentile(kl[ok], 90):6.2f} |"
+          f" {ep[ok].mean():7.2f} {np.percentile(ep[ok], 90):6.2f} | {100 * (pro[ok].sum() + ep[ok].sum()) / (pro[ok].sum() + kl[ok].sum() + ep[ok].sum()):9.1f} % | {first}")
+syn.close()

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p summertts_amd/lib/var
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form"
 for m in "$@"; do
-  /opt/rocm/bin/hipcc $F -DSTS_VAR=$m -c summertts_amd/csrc/conv_bf3.hip -o summertts_amd/lib/var/conv_bf3_$m.o &
+  /opt/rocm/bin/hipcc $F $VAR_EXTRA -DSTS_VAR=$m -c summertts_amd/csrc/conv_bf3.hip -o summertts_amd/lib/var/conv_bf3_$m.o &
 done
 wait
 O=summertts_amd/lib/obj
