@@ -122,9 +122,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     if (g_tile_trace && threadIdx.x == 0) {
         const unsigned slot = atomicAdd(&g_tile_trace_n, 1u);
         if (slot < g_tile_trace_cap) {
-            tt_rec = g_tile_trace + (size_t)slot * 8;
+            tt_rec = g_tile_trace + (size_t)slot * 10;
             tt_rec[0] = (long long)gridDim.x; tt_rec[1] = (long long)blockIdx.x;
-            tt_rec[2] = (long long)((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf) << 16 | (__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) & 0xffff));
+            tt_rec[2] = 0;        // kernel tag: 0 = staged conv (stamps: start, first barrier, K loop done, epilogue done)
             tt_rec[3] = (long long)__builtin_amdgcn_s_memrealtime();
         }
     }
@@ -400,6 +400,19 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const TileId t = map_tile(nx, 1, G.B * G.n);
     if (!t.valid) return;
+#ifdef STS_TILE_TRACE
+    long long* tt_rec = nullptr;
+    if (g_tile_trace && threadIdx.x == 0) {
+        const unsigned slot = atomicAdd(&g_tile_trace_n, 1u);
+        if (slot < g_tile_trace_cap) {
+            tt_rec = g_tile_trace + (size_t)slot * 10;
+            tt_rec[0] = (long long)gridDim.x; tt_rec[1] = (long long)blockIdx.x;
+            tt_rec[2] = 1;        // fused layer (stamps: start, window staged, conv1 done, intermediate parked, conv2 done, epilogue done)
+            tt_rec[3] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+    }
+    TT_STAMP(0);
+#endif
     int gi, tbx, b;
     if (interleave) { const int unit = t.bz * nx + t.bx; gi = unit % G.n; const int rest = unit / G.n; tbx = rest % nx; b = rest / nx; }
     else { gi = t.bz / G.B; tbx = t.bx; b = t.bz - gi * G.B; }
@@ -475,6 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                 for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(ac[i][kProdA[p]], bc[q][kProdB[p]], acc[i][q]);
     };
     __syncthreads();
+    TT_STAMP(1);
 
     // ================= phase 1: conv1 on the P1 columns [n0 - h2, n0 - h2 + P1) =================
     {
@@ -514,6 +528,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                 }
             });
     }
+    TT_STAMP(2);
     __syncthreads();          // every wave is done reading the staged window (the parked intermediate overwrites it)
     // ---- park: bias, conv2's input activation, conv2's zero padding outside [0, len), split
     static_for<0, MW>([&](auto ic) {
@@ -551,6 +566,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
         });
     });
     __syncthreads();
+    TT_STAMP(3);
 
     // ================= phase 2: conv2 (dilation 1) out of the parked intermediate =================
     {
@@ -590,6 +606,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                 }
             });
     }
+    TT_STAMP(4);
     // ---- epilogue: + b2 + x (the residual is re-read: the staged copy was activated and split).  As in tile_epilogue
     // (conv_common.hpp): a 4 x 4 transpose inside the lane quads turns a lane's 4 consecutive rows of one column into 4 consecutive
     // columns of one row, so the tile's residual arrives and its result leaves through 16-byte accesses (a quarter of the memory
@@ -632,6 +649,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
             });
         });
     }
+#ifdef STS_TILE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TT_STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

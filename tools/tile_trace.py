@@ -27,14 +27,14 @@ for _ in range(3):
     syn.run_batch(ids)
 lib = syn.lib
 cap = 1 << 17
-buf = torch.zeros(cap * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(cap * 10, dtype=torch.int64, device="cuda")
 lib.sts_debug_tile_trace.argtypes = [C.c_void_p, C.c_uint]
 assert lib.sts_debug_tile_trace(buf.data_ptr(), cap) == 0
 syn.run_batch(ids)
 torch.cuda.synchronize()
 n = lib.sts_debug_tile_trace_count()
 lib.sts_debug_tile_trace(None, 0)
-r = buf.cpu().numpy().reshape(-1, 8)[:min(n, cap)]
+r = buf.cpu().numpy().reshape(-1, 10)[:min(n, cap)]
 print(f"{n} workgroup records, batch {B}; s_memtime tick assumed {TICK} ns (shader clock), real-time tick 10 ns")
 order = np.argsort(r[:, 3], kind="stable")
 r = r[order]
@@ -46,16 +46,27 @@ for i in range(1, len(r)):
     else:
         cur.append(i)
 launches.append(cur)
-print(" launch  grid_wgs  recorded  span_us | prologue mean/p90 | K loop mean/p90 | epilogue mean/p90 | non-K share | started in first 2 us")
+print(" launch kind   wgs  span_us | phases (mean us, p90 in brackets)                                                       | non-MFMA share | started in first 2 us")
 for li, idx in enumerate(launches):
     q = r[idx]
-    pro = (q[:, 5] - q[:, 4]) * TICK / 1e3; kl = (q[:, 6] - q[:, 5]) * TICK / 1e3; ep = (q[:, 7] - q[:, 6]) * TICK / 1e3
-    ok = (q[:, 7] > 0) & (q[:, 6] > 0)
+    kind = int(q[0, 2])
+    last = 9 if kind == 1 else 7
+    ok = (q[:, last] > 0) & (q[:, 5] > 0)
     if not ok.any():
         continue
+    q = q[ok]
     t0 = (q[:, 3] - q[:, 3].min()) * 10e-3
-    end = t0 + (q[:, 7] - q[:, 4]) * TICK / 1e3
+    end = t0 + (q[:, last] - q[:, 4]) * TICK / 1e3
     first = int((t0 < 2.0).sum())
-    print(f"{li:7d} {int(q[0, 0]) // 256:9d} {len(idx):9d} {end[ok].max():8.1f} | {pro[ok].mean():7.2f} {np.percentile(pro[ok], 90):6.2f} | {kl[ok].mean():7.2f} {np.percentile(kl[ok], 90):6.2f} |"
-          f" {ep[ok].mean():7.2f} {np.percentile(ep[ok], 90):6.2f} | {100 * (pro[ok].sum() + ep[ok].sum()) / (pro[ok].sum() + kl[ok].sum() + ep[ok].sum()):9.1f} % | {first}")
+    d = lambda a, b: (q[:, b] - q[:, a]) * TICK / 1e3
+    f = lambda v: f"{v.mean():6.2f} ({np.percentile(v, 90):6.2f})"
+    if kind == 0:
+        pro, kl, ep = d(4, 5), d(5, 6), d(6, 7)
+        ph = f"prologue {f(pro)}  K loop {f(kl)}  epilogue {f(ep)}"
+        share = 100 * (pro.sum() + ep.sum()) / (pro.sum() + kl.sum() + ep.sum())
+    else:
+        st, c1, pk, c2, ep = d(4, 5), d(5, 6), d(6, 7), d(7, 8), d(8, 9)
+        ph = f"stage {f(st)}  conv1 {f(c1)}  park {f(pk)}  conv2 {f(c2)}  epilogue {f(ep)}"
+        share = 100 * (st.sum() + pk.sum() + ep.sum()) / (st.sum() + c1.sum() + pk.sum() + c2.sum() + ep.sum())
+    print(f"{li:7d} {'fused' if kind else 'conv '} {len(q):5d} {end.max():8.1f} | {ph:110s} | {share:9.1f} % | {first}")
 syn.close()
