@@ -46,7 +46,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //   4  plain tiles: step index == position in the packed weights ......... /
 //   8  a step's LDS reads / weight loads interleaved with its MFMAs (sched_group_barrier) ... no effect
 //   16 weight fragments requested two steps ahead (ring of 3, 214 VGPRs) .................... no effect
-// i.e. the kernel is bound neither by instruction issue in the staging / bookkeeping code nor by weight latency.
+//   32 weight loads AND LDS reads of the next step issued between this step's MFMAs (one basic block, 2 MFMA : 1 memory op) ..
+//      +7 % SLOWER (a lone workgroup's step 1 500 -> 1 900 cycles: anything placed between MFMAs of one accumulator chain costs
+//      more than its issue slot, and the fragments are requested later)
+// i.e. the kernel is bound neither by instruction issue in the staging / bookkeeping code nor by weight latency; a lone wave needs
+// ~1 500 cycles per 24-MFMA step (768 pipe cycles), two waves per SIMD ~1 650 each = the pipe 94 % busy during K loops
+// (tools/tile_trace_conv.py, profiles/r03_tile_trace_conv_kloop_per_step.log): what is left is outside the K loop.
 #ifndef STS_VAR
 #define STS_VAR 6
 #endif
@@ -124,7 +129,8 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         if (slot < g_tile_trace_cap) {
             tt_rec = g_tile_trace + (size_t)slot * 10;
             tt_rec[0] = (long long)gridDim.x; tt_rec[1] = (long long)blockIdx.x;
-            tt_rec[2] = 0;        // kernel tag: 0 = staged conv (stamps: start, first barrier, K loop done, epilogue done)
+            // kernel tag 0 = staged conv (stamps: start, first barrier, K loop done, epilogue done) | HW_ID << 8 | XCC_ID << 40
+            tt_rec[2] = ((long long)(__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4)) & 0xffffffffll) << 8 | (long long)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf) << 40;
             tt_rec[3] = (long long)__builtin_amdgcn_s_memrealtime();
         }
     }
@@ -264,22 +270,26 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     auto a_index = [&](int c, int sub, int j) { return (c * NSUB + sub) * a.ntap + j; };
     auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
         int nj = sj + 1, nsub = ssub, nc = sc;
-        if ((STS_VAR & (4 | 16)) && NSUB == 1 && KG == 1) {
+        const bool late_a = (STS_VAR & 32) != 0;       // request the next step's weight fragments in the same block as the MFMAs
+        int a_next;
+        if ((STS_VAR & (4 | 16 | 32)) && NSUB == 1 && KG == 1) {
             // one sub-chunk, one wave group: the step index IS the position in the packed weights, only (tap, chunk) are tracked
             if (nj == a.ntap) { nj = 0; nc = sc + 1; }
             nsub = 0;
-            if (!(STS_EXP & 2) || s < 2) load_a(s + AR - 1, anew);
+            a_next = s + AR - 1;
         } else {
-        if (nj == a.ntap) { nj = 0; nsub = ssub + KG; if (nsub >= NSUB) { nsub = kg; nc = sc + 1; } }
-        if (!(STS_EXP & 2) || s < 2) load_a(a_index(nc, nsub, nj), anew);   // unconditional: past the last step it reads 0 beyond the descriptor, never used
+            if (nj == a.ntap) { nj = 0; nsub = ssub + KG; if (nsub >= NSUB) { nsub = kg; nc = sc + 1; } }
+            a_next = a_index(nc, nsub, nj);
         }
+        if (!late_a && (!(STS_EXP & 2) || s < 2)) load_a(a_next, anew);   // unconditional: past the last step it reads 0 beyond the descriptor, never used
         if (nc != sc && s + 1 < nsteps) {
             store_tile(nc & 1);           // chunk nc's tile (in registers since the start of chunk sc)
             if (!(STS_EXP & 4)) __syncthreads();              // tile nc visible; everyone is done reading the buffer it replaces
             if (nc + 1 < nchunk) load_x(nc + 1);
         }
+        if (late_a) load_a(a_next, anew);
         if (!(STS_EXP & 16) || s < 2) load_b(nc & 1, nsub, nj, bnxt);   // past the last step: stale LDS inside the tile, never used
-        if (!(STS_VAR & 1)) __builtin_amdgcn_sched_barrier(0);
+        if (!(STS_VAR & (1 | 32))) __builtin_amdgcn_sched_barrier(0);
         if (!(STS_EXP & 64))
 #pragma unroll
         for (int p = 0; p < 6; p++)
@@ -287,13 +297,14 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             for (int i = 0; i < MW; i++)
 #pragma unroll
                 for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(acur[i][kProdA[p]], bcur[q][kProdB[p]], acc[i][q]);
-        if (STS_VAR & 8) {
+        if (STS_VAR & (8 | 32)) {
             // the step's 6 LDS reads and 6 weight loads spread between its MFMAs (2 MFMAs per memory operation)
 #pragma unroll
-            for (int r = 0; r < 6 * MW * NW / 2; r++) {
+            for (int r = 0; r < 6 * MW * NW / 4; r++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
             }
         }
         sj = nj; ssub = nsub; sc = nc;

@@ -49,7 +49,7 @@ launches.append(cur)
 print(" launch kind   wgs  span_us | phases (mean us, p90 in brackets)                                                       | non-MFMA share | started in first 2 us")
 for li, idx in enumerate(launches):
     q = r[idx]
-    kind = int(q[0, 2])
+    kind = int(q[0, 2]) & 0xff
     last = 9 if kind == 1 else 7
     ok = (q[:, last] > 0) & (q[:, 5] > 0)
     if not ok.any():
@@ -69,4 +69,18 @@ for li, idx in enumerate(launches):
         ph = f"stage {f(st)}  conv1 {f(c1)}  park {f(pk)}  conv2 {f(c2)}  epilogue {f(ep)}"
         share = 100 * (st.sum() + pk.sum() + ep.sum()) / (st.sum() + c1.sum() + pk.sum() + c2.sum() + ep.sum())
     print(f"{li:7d} {'fused' if kind else 'conv '} {len(q):5d} {end.max():8.1f} | {ph:110s} | {share:9.1f} % | {first}")
+# placement: which workgroups share a CU?  (HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC id on top)
+if os.environ.get("TT_PLACEMENT"):
+    li = int(os.environ["TT_PLACEMENT"])
+    q = r[launches[li]]
+    hw = (q[:, 2] >> 8) & 0xffffffff
+    xcc = (q[:, 2] >> 40) & 0xf
+    cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (xcc << 8)
+    t0 = (q[:, 3] - q[:, 3].min()) * 10e-3
+    print(f"placement of launch {li}: {len(np.unique(cu))} distinct CU ids")
+    by = {}
+    for blk, c, tt, kl in zip(q[:, 1], cu, t0, (q[:, 6] - q[:, 5]) * TICK / 1e3):
+        by.setdefault(int(c), []).append((int(blk), round(float(tt), 1), round(float(kl), 1)))
+    for c in sorted(by)[:48]:
+        print(f"  cu {c:5d} (xcc {c >> 8}): " + "  ".join(f"blk {b_:4d} t0 {t_:5.1f} K {k_:5.1f}" for b_, t_, k_ in sorted(by[c], key=lambda z: z[1])))
 syn.close()
