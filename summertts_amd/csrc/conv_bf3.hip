@@ -579,6 +579,31 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     __syncthreads();
     TT_STAMP(3);
 
+    // The residual (raw x of the output columns; the staged copy was activated and split) and conv2's bias are requested BEFORE
+    // conv2's K loop, in the transposed-quad layout of the epilogue below: they arrive under the MFMAs instead of costing the
+    // epilogue a memory round trip (round 3, tools/tile_trace.py: epilogue 4.4 us of a 19 us 32-channel tile)
+    const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
+    f32x4u xres[MW][NW][4];
+    float b2v[MW][4];
+#pragma unroll
+    for (int i = 0; i < MW; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int row = mbase + i * 32 + 8 * g + 4 * half + lane4;
+            b2v[i][g] = a.b2 ? a.b2[row] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const int col = wn * NW * 32 + q * 32 + m4;
+                const int pos = n0 + col;
+                xres[i][q][g] = f32x4u{0.f, 0.f, 0.f, 0.f};
+                if (col < NT && pos < len) {
+                    const float* xp = a.x + (size_t)row * G.ld + base + pos;
+                    if (col + 3 < NT && pos + 3 < len) xres[i][q][g] = *(const f32x4u*)xp;
+                    else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) xres[i][q][g][e] = xp[e]; }
+                }
+            }
+        }
+
     // ================= phase 2: conv2 (dilation 1) out of the parked intermediate =================
     {
         const int nsteps = NCH * a.k2;
@@ -623,27 +648,13 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     // columns of one row, so the tile's residual arrives and its result leaves through 16-byte accesses (a quarter of the memory
     // instructions; the epilogue was store-issue-bound)
     {
-        const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
         static_for<0, MW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            int rowv[4]; float b2v[4];
-#pragma unroll
-            for (int g = 0; g < 4; g++) { rowv[g] = mbase + i * 32 + 8 * g + 4 * half + lane4; b2v[g] = a.b2 ? a.b2[rowv[g]] : 0.f; }
             static_for<0, NW>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 const int col = wn * NW * 32 + q * 32 + m4;
                 const int pos = n0 + col;
                 const bool any = col < NT && pos < len, full = col + 3 < NT && pos + 3 < len;
-                f32x4u xv[4];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    xv[g] = f32x4u{0.f, 0.f, 0.f, 0.f};
-                    if (any) {
-                        const float* xp = a.x + (size_t)rowv[g] * G.ld + base + pos;
-                        if (full) xv[g] = *(const f32x4u*)xp;
-                        else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) xv[g][e] = xp[e]; }
-                    }
-                }
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     float w[4] = {acc[i][q][4 * g], acc[i][q][4 * g + 1], acc[i][q][4 * g + 2], acc[i][q][4 * g + 3]};
@@ -651,8 +662,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                     if (any) {
                         f32x4u o;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) o[e] = w[e] + b2v[g] + xv[g][e];
-                        float* yp = a.y + (size_t)rowv[g] * G.ld + base + pos;
+                        for (int e = 0; e < 4; e++) o[e] = w[e] + b2v[i][g] + xres[i][q][g][e];
+                        float* yp = a.y + (size_t)(mbase + i * 32 + 8 * g + 4 * half + lane4) * G.ld + base + pos;
                         if (full) *(f32x4u*)yp = o;
                         else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) yp[e] = o[e]; }
                     }
