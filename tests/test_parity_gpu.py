@@ -773,3 +773,36 @@ def test_multi_device_rccl_gather_with_a_one_rank_communicator():
         assert_pcm_close(g, w, f"download, utterance {i}")
     for g, w in zip(got, got1):
         assert np.array_equal(g, w)          # same shard, same engine path: the gather itself must not change a sample
+
+
+def test_persistent_flow_kernels_of_several_engines_do_not_deadlock():
+    """persist.hip never waits for a workgroup that is not resident: three engines on ONE GPU run their persistent flow kernels
+    (256 workgroups x 16 waves each -- one alone fills the chip) from three host threads at the same time, twenty calls each; a
+    barrier-style kernel would hang as soon as two of them interleave.  Results must equal the single-engine result."""
+    import threading
+    cfg = sb.full_cfg("hifigan_sdp")
+    blob = sb.make_blob(cfg, 1234)
+    ids = sb.synthetic_ids(96, cfg.vocab, salt=2)
+    engines = [engine.Synthesizer(blob) for _ in range(3)]
+    for e in engines:
+        e.debug_set("front_mode", 2)
+    want = engines[0].infer_ids(ids, 0, 1.0)
+    out, err = [None] * 3, []
+
+    def work(k):
+        try:
+            for _ in range(20):
+                out[k] = engines[k].infer_ids(ids, 0, 1.0)
+        except Exception as ex:      # noqa: BLE001
+            err.append(ex)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "persistent flow kernels of concurrent engines hang"
+    assert not err, err
+    for k in range(3):
+        assert np.array_equal(out[k], want)
+    for e in engines:
+        e.close()
