@@ -371,20 +371,49 @@ struct BufF {
     int16_t* pcm;
 };
 
-int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss) {
-    Model& M = model;
-    if (B <= 0 || !ids || !n) return fail(STS_EINVAL, "empty batch");
-    if (ss && (B != 1 || ss->chunk_frames <= 0 || !ss->cb)) return fail(STS_EINVAL, "streaming takes one utterance, a positive chunk size and a callback");
-    HIPCK(hipSetDevice(device));
-    taps.clear();
-    memset(&prof, 0, sizeof(prof));
-    for (double& f : flops_) f = 0;
-    for (double& f : bytes_) f = 0;
-    mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+// Everything a run's stages share: batch geometry, workspace pointers, host / device tables.  Engine::run() fills it stage by
+// stage; the stage functions below see its fields under the names the pipeline has always used (RUN_ALIASES).
+struct Engine::RunCtx {
+    int B = 0; const int32_t* const* ids = nullptr; const int32_t* n = nullptr; const int32_t* sid = nullptr; const float* ls = nullptr;
+    const StreamSpec* ss = nullptr;
+    std::vector<int> offT, lenT; long Ttot = 0; int maxT = 0;
+    int H = 0, C = 0, FF = 0, fdp = 0, wnH = 0, wnL = 0, ffn2_slices = 1;
+    Lvl lvT, lvB, lv1;
+    BufT bt; BufF bf;
+    size_t meta_ints = 0, up_bytes = 0;
+    int *pm = nullptr, *p_offT = nullptr, *p_lenT = nullptr, *p_sid = nullptr, *p_offF = nullptr, *p_lenF = nullptr, *p_one = nullptr;
+    int *d_offT = nullptr, *d_lenT = nullptr, *d_sid = nullptr, *d_offF = nullptr, *d_lenF = nullptr, *d_one = nullptr, *d_win = nullptr;
+    bool inl = false, no_inline_seg = false, ms = false;
+    long Ftot = 0; int maxF = 0, hop = 0;
+    int halo = 0; long Wcap = 0; int upS = 1; long Lsb = 0; int sbC = 0;
+    bool use_pk = false; int pk_fs = 0, pk_wld = 0, pk_rows = 0;
+};
+#define RUN_ALIASES(c)                                                                                                              \
+    [[maybe_unused]] Model& M = model;                                                                                              \
+    [[maybe_unused]] const int B = (c).B; [[maybe_unused]] const StreamSpec* const ss = (c).ss;                                     \
+    [[maybe_unused]] const long Ttot = (c).Ttot; [[maybe_unused]] const int maxT = (c).maxT;                                        \
+    [[maybe_unused]] const int H = (c).H, C = (c).C, FF = (c).FF, fdp = (c).fdp, wnH = (c).wnH, wnL = (c).wnL, ffn2_slices = (c).ffn2_slices; \
+    [[maybe_unused]] Lvl &lvT = (c).lvT, &lvB = (c).lvB, &lv1 = (c).lv1;                                                            \
+    [[maybe_unused]] BufT& bt = (c).bt; [[maybe_unused]] BufF& bf = (c).bf;                                                         \
+    [[maybe_unused]] const size_t up_bytes = (c).up_bytes;                                                                          \
+    [[maybe_unused]] int* const pm = (c).pm; [[maybe_unused]] int* const p_offF = (c).p_offF; [[maybe_unused]] int* const p_lenF = (c).p_lenF; \
+    [[maybe_unused]] int* const d_sid = (c).d_sid; [[maybe_unused]] int* const d_offF = (c).d_offF; [[maybe_unused]] int* const d_lenF = (c).d_lenF; \
+    [[maybe_unused]] int* const d_win = (c).d_win;                                                                                  \
+    [[maybe_unused]] const bool inl = (c).inl, no_inline_seg = (c).no_inline_seg, ms = (c).ms;                                      \
+    [[maybe_unused]] const long Ftot = (c).Ftot; [[maybe_unused]] const int maxF = (c).maxF, hop = (c).hop;                         \
+    [[maybe_unused]] const int halo = (c).halo; [[maybe_unused]] const long Wcap = (c).Wcap, Lsb = (c).Lsb;                         \
+    [[maybe_unused]] const int upS = (c).upS, sbC = (c).sbC;                                                                        \
+    [[maybe_unused]] const bool use_pk = (c).use_pk; [[maybe_unused]] const int pk_fs = (c).pk_fs, pk_wld = (c).pk_wld, pk_rows = (c).pk_rows;
 
+// ---- stage 0: batch geometry at the phoneme level, phoneme-level workspace, the one host-to-device copy of a run
+int Engine::run_setup(RunCtx& c) {
+    Model& M = model;
+    const int B = c.B; const int32_t* const* ids = c.ids; const int32_t* n = c.n; const int32_t* sid = c.sid; const float* ls = c.ls;
     // ---------------- host-side batch geometry (phoneme level)
-    std::vector<int> offT(B), lenT(B);
-    long Ttot = 0; int maxT = 0;
+    std::vector<int>& offT = c.offT; std::vector<int>& lenT = c.lenT;
+    offT.assign(B, 0); lenT.assign(B, 0);
+    long& Ttot = c.Ttot; int& maxT = c.maxT;
+    Ttot = 0; maxT = 0;
     for (int b = 0; b < B; b++) {
         if (n[b] <= 0 || !ids[b]) return fail(STS_EINVAL, "utterance with no phonemes");
         for (int i = 0; i < n[b]; i++)
@@ -395,15 +424,15 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     if ((size_t)(M.hidden / 2 + 8 + 5 * (size_t)maxT) * 4 > 150 * 1024) return fail(STS_EINVAL, "utterance too long for the attention kernel");
     if (have_forced && (long)forced_dur.size() != Ttot) { have_forced = false; return fail(STS_EINVAL, "forced durations do not match the batch"); }
 
-    const int H = M.hidden, C = M.inter;
-    const int FF = M.n_layers ? M.ffn[0].c1.Cout : 0;
-    const int fdp = M.dur_type == 0 ? M.sdp_pre.Cout : M.fix_c1.Cout;
-    const int wnH = M.n_flows ? M.cp[0].wn.H : 0;
-    const int wnL = M.n_flows ? M.cp[0].wn.n : 0;
+    const int H = c.H = M.hidden, C = c.C = M.inter;
+    const int FF = c.FF = M.n_layers ? M.ffn[0].c1.Cout : 0;
+    const int fdp = c.fdp = M.dur_type == 0 ? M.sdp_pre.Cout : M.fix_c1.Cout;
+    const int wnH = c.wnH = M.n_flows ? M.cp[0].wn.H : 0;
+    const int wnL = c.wnL = M.n_flows ? M.cp[0].wn.n : 0;
 
-    Lvl lvT; lvT.nb = B; lvT.max_len = maxT; lvT.total = Ttot; lvT.ld = Ttot;
-    const int ffn2_slices = M.n_layers ? pick_kslices(M.ffn[0].c2, lvT) : 1;
-    BufT bt;
+    Lvl& lvT = c.lvT; lvT = Lvl(); lvT.nb = B; lvT.max_len = maxT; lvT.total = Ttot; lvT.ld = Ttot;
+    const int ffn2_slices = c.ffn2_slices = M.n_layers ? pick_kslices(M.ffn[0].c2, lvT) : 1;
+    BufT& bt = c.bt;
     auto layoutT = [&](Arena& A) {
         A.used = 0;
         // one device block mirroring the pinned staging block [geometry ints | length scales | ids | forced durations]:
@@ -433,15 +462,16 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     arenaT_.measuring = false; layoutT(arenaT_);
 
     // ---------------- one H2D: geometry + ids (+ forced durations)
-    const size_t meta_ints = (size_t)9 * B + 8;
-    const size_t up_bytes = (meta_ints + B + 2 * (size_t)Ttot) * 4 + 1024;
+    const size_t meta_ints = c.meta_ints = (size_t)9 * B + 8;
+    const size_t up_bytes = c.up_bytes = (meta_ints + B + 2 * (size_t)Ttot) * 4 + 1024;
     if (!ensure_pinned(up_bytes + ((size_t)Ttot + B) * 4)) return fail(STS_EDEVICE, "pinned host allocation failed");
-    int* pm = (int*)pinned_;
-    int* p_offT = pm, *p_lenT = pm + B, *p_sid = pm + 2 * B, *p_offF = pm + 3 * B, *p_lenF = pm + 4 * B, *p_one = pm + 5 * B;
+    int* pm = c.pm = (int*)pinned_;
+    int* p_offT = c.p_offT = pm, *p_lenT = c.p_lenT = pm + B, *p_sid = c.p_sid = pm + 2 * B, *p_one = c.p_one = pm + 5 * B;
+    c.p_offF = pm + 3 * B; c.p_lenF = pm + 4 * B;
     for (int b = 0; b < B; b++) { p_offT[b] = offT[b]; p_lenT[b] = lenT[b]; p_sid[b] = sid ? sid[b] : 0; }
     p_one[0] = 0; p_one[1] = B;
-    int* d_offT = bt.meta_i, *d_lenT = bt.meta_i + B, *d_sid = bt.meta_i + 2 * B, *d_offF = bt.meta_i + 3 * B,
-        *d_lenF = bt.meta_i + 4 * B, *d_one = bt.meta_i + 5 * B;
+    int* d_offT = c.d_offT = bt.meta_i, *d_lenT = c.d_lenT = bt.meta_i + B, *d_one = c.d_one = bt.meta_i + 5 * B;
+    c.d_sid = bt.meta_i + 2 * B; c.d_offF = bt.meta_i + 3 * B; c.d_lenF = bt.meta_i + 4 * B; c.d_win = bt.meta_i + 5 * B + 2;
     float* p_ls = (float*)(pm + meta_ints);
     for (int b = 0; b < B; b++) p_ls[b] = ls ? ls[b] : 1.0f;
     int* p_ids = (int*)(p_ls + B);
@@ -451,13 +481,20 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     HIPCK(hipMemcpyAsync(bt.meta_i, pm, (meta_ints + B + (size_t)Ttot * (have_forced ? 2 : 1)) * 4, hipMemcpyHostToDevice, stream));
 
     // single-segment views travel by value (kernels.hpp SegView): no segment-table load in the kernels of a one-utterance call
-    static const bool no_inline_seg = exp_flag("STS_NO_INLINE_SEG");   // experiment knob
-    const bool inl = B == 1 && !no_inline_seg;
+    static const bool no_inline_seg_knob = exp_flag("STS_NO_INLINE_SEG");   // experiment knob
+    const bool no_inline_seg = c.no_inline_seg = no_inline_seg_knob;
+    const bool inl = c.inl = B == 1 && !no_inline_seg;
+    c.ms = M.is_ms == 1;
     lvT.seg = inl ? SegView{nullptr, nullptr, 1, 0, 0, lenT[0]} : SegView{d_offT, d_lenT, 1, 0, 0, 0};
-    Lvl lvB; lvB.seg = no_inline_seg ? SegView{d_one, d_one + 1, 1, 0, 0, 0} : SegView{nullptr, nullptr, 1, 0, 0, B};
+    Lvl& lvB = c.lvB; lvB = Lvl(); lvB.seg = no_inline_seg ? SegView{d_one, d_one + 1, 1, 0, 0, 0} : SegView{nullptr, nullptr, 1, 0, 0, B};
     lvB.nb = 1; lvB.max_len = B; lvB.total = B; lvB.ld = B;
 
-    mark(0);
+    return STS_OK;
+}
+
+// ---- stage 1: TextEncoder (/root/reference/src/models/TextEncoder.cpp:50-74, attention_encoder.cpp:78-94)
+int Engine::run_text_encoder(RunCtx& c) {
+    RUN_ALIASES(c)
     // ---------------- TextEncoder (/root/reference/src/models/TextEncoder.cpp:50-74, attention_encoder.cpp:78-94)
     stage_begin(0);
     // The producer of a layer's input x -- the embedding for layer 0, the previous layer's second LayerNorm (which also adds
@@ -531,10 +568,21 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     tap("x_enc", bt.x, H, Ttot, Ttot);
     tap("m", bt.m, C, Ttot, Ttot);
     mark(1);
+    return STS_OK;
+}
+
+// ---- stage 2: speaker conditioning, duration predictor, durations -> frame counts on the host (the one data-dependent sync)
+int Engine::run_durations(RunCtx& c) {
+    Model& M = model;
+    const int B = c.B; const StreamSpec* const ss = c.ss; const long Ttot = c.Ttot;
+    [[maybe_unused]] const int H = c.H, fdp = c.fdp;
+    Lvl &lvT = c.lvT, &lvB = c.lvB; BufT& bt = c.bt;
+    const size_t up_bytes = c.up_bytes; int* const pm = c.pm; int* const p_offF = c.p_offF; int* const p_lenF = c.p_lenF;
+    int* const d_sid = c.d_sid; int* const d_offF = c.d_offF;
+    const bool inl = c.inl, ms = c.ms; const int maxT = c.maxT; (void)maxT;
 
     // ---------------- speaker conditioning vectors (all 1x1 convs on g; SynthesizerTrn.cpp:363-372)
     stage_begin(1);
-    const bool ms = M.is_ms == 1;
     if (ms) gather_speaker(M.emb_g, M.spk_num, M.gin, d_sid, B, bt.g, stream);
 
     // ---------------- duration predictor
@@ -629,12 +677,13 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     }
     durations_h.assign(p_down, p_down + Ttot);
     tap("logw", bt.dlogw, 1, Ttot, Ttot);
-    long Ftot = 0; int maxF = 0;
+    long& Ftot = c.Ftot; int& maxF = c.maxF;
+    Ftot = 0; maxF = 0;
     for (int b = 0; b < B; b++) {
         int f = p_down[Ttot + b];
         p_offF[b] = (int)Ftot; p_lenF[b] = f; Ftot += f; if (f > maxF) maxF = f;
     }
-    const int hop = M.hop_total;
+    const int hop = c.hop = M.hop_total;
     if ((double)Ftot * hop > 2.0e9 || (double)Ftot * hop * 8 > 6.0e10) return fail(STS_EINVAL, "batch produces too many samples for one call");
     {   // frame geometry + (normal call) the decode windows = the utterances, in the same copy
         int* pw = pm + 5 * B + 2;
@@ -653,28 +702,38 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         }
     }
 
+    return STS_OK;
+}
+
+// ---- stage 3: frame-level workspace (flow buffers over all frames, decoder buffers over the decode windows)
+int Engine::run_frame_workspace(RunCtx& c) {
+    Model& M = model;
+    const int B = c.B; const StreamSpec* const ss = c.ss; const long Ftot = c.Ftot; const int maxF = c.maxF, hop = c.hop;
+    const int C = c.C, wnH = c.wnH; const bool inl = c.inl;
+    int* const p_lenF = c.p_lenF; int* const d_offF = c.d_offF; int* const d_lenF = c.d_lenF;
     // ---------------- frame-level workspace.  The flow works on all Ftot frames; the decoder works on
     // "windows" of z: whole utterances normally (Wcap == Ftot), one chunk plus its two halos when streaming.
-    const int halo = decoder_halo_frames(M);
-    const long Wcap = ss ? std::min<long>(Ftot, (long)ss->chunk_frames + 2 * halo) : Ftot;
+    const int halo = c.halo = decoder_halo_frames(M);
+    const long Wcap = c.Wcap = ss ? std::min<long>(Ftot, (long)ss->chunk_frames + 2 * halo) : Ftot;
     int upS = 1;
     for (int u : M.up_rate) upS *= u;
+    c.upS = upS;
     std::vector<size_t> stage_elems(M.n_up);
     size_t regA = 0, regB = 0;
     { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)(1 + 3 * M.n_resk) * M.ups[i].Cout * Wcap * S;
           if (i & 1) { if (stage_elems[i] > regB) regB = stage_elems[i]; } else { if (stage_elems[i] > regA) regA = stage_elems[i]; } } }
-    const long Lsb = Wcap * upS + B;           // MB-iSTFT: frames + 1 per window
-    const int sbC = M.conv_post.Cout;
+    const long Lsb = c.Lsb = Wcap * upS + B;           // MB-iSTFT: frames + 1 per window
+    const int sbC = c.sbC = M.conv_post.Cout;
     // one utterance: the whole flow as ONE persistent launch, the frame axis cut into one window per XCD (persist.hip).  Measured on
     // MI355X (profiles/r03_pk_flow_trace.log): correct and deadlock-free, but at 128 phonemes it takes 0.50 ms against
     // 0.44 ms for the 41 launches -- an op inside the persistent kernel still costs ~6 us of dependent latencies (claim, operand
     // round trips, partial-sum exchange, store acknowledgement, completion poll) and the gate convs are fp32-MFMA-bound on windows
     // that overlap 1.77x -- so the launch-per-layer path stays the default and this one is opt-in: front_mode 2 (sts_debug_set)
-    const bool use_pk = B == 1 && !M.cp.empty() && front_mode == 2 && conv_mode == 0 && conv_math != 2 && Ftot <= 16384 && flow_program();
-    const int pk_fs = (int)((Ftot + 7) / 8);
-    const int pk_wld = (pk_fs + 2 * pk_halo_ + 31) / 32 * 32 + 32;
-    const int pk_rows = C > wnH ? C : wnH;
-    BufF bf;
+    const bool use_pk = c.use_pk = B == 1 && !M.cp.empty() && front_mode == 2 && conv_mode == 0 && conv_math != 2 && Ftot <= 16384 && flow_program();
+    const int pk_fs = c.pk_fs = (int)((Ftot + 7) / 8);
+    const int pk_wld = c.pk_wld = (pk_fs + 2 * pk_halo_ + 31) / 32 * 32 + 32;
+    const int pk_rows = c.pk_rows = C > wnH ? C : wnH;
+    BufF& bf = c.bf;
     auto layoutF = [&](Arena& A) {
         A.used = 0;
         bf.pk = A.get<float>(use_pk ? (size_t)8 * 4 * pk_rows * pk_wld : 1);
@@ -695,9 +754,16 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     if (!ensure(arenaF_, arenaF_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (frame-level workspace)");
     arenaF_.measuring = false; layoutF(arenaF_);
 
-    Lvl lv1; lv1.seg = inl ? SegView{nullptr, nullptr, 1, 0, 0, p_lenF[0]} : SegView{d_offF, d_lenF, 1, 0, 0, 0};
+    Lvl& lv1 = c.lv1; lv1 = Lvl(); lv1.seg = inl ? SegView{nullptr, nullptr, 1, 0, 0, p_lenF[0]} : SegView{d_offF, d_lenF, 1, 0, 0, 0};
     lv1.nb = B; lv1.max_len = maxF; lv1.total = Ftot; lv1.ld = Ftot;
     mark(7);
+    (void)pk_fs; (void)pk_wld; (void)pk_rows;
+    return STS_OK;
+}
+
+// ---- stage 4: length regulator + reverse flow
+int Engine::run_flow(RunCtx& c) {
+    RUN_ALIASES(c)
     // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
     stage_begin(2);
     const int half = C / 2;
@@ -777,15 +843,18 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     if (M.n_flows & 1) flip_channels(bf.z, Ftot, C, Ftot, bf.fliptmp, stream);
     tap("z", bf.z, C, Ftot, Ftot);
     mark(3);
+    return STS_OK;
+}
 
-    // ---------------- decoder trunk (Generator_hifigan.cpp:139-175 and the identical loops of MS/Istft/MBB)
-    // One decode pass over `nw` windows of z.  Window w covers frames [zoff[w], zoff[w] + wlen[w]) of the packed z
-    // and owns the compact range starting at coff[w] in every decoder buffer.  (Normal call: the windows ARE the
-    // utterances and zoff == coff == offF.)  d_win = device ints {zoff[nw], coff[nw], wlen[nw]}.
+// ---- stage 5: one decode pass over `nw` windows of z
+// ---------------- decoder trunk (Generator_hifigan.cpp:139-175 and the identical loops of MS/Istft/MBB)
+// One decode pass over `nw` windows of z.  Window w covers frames [zoff[w], zoff[w] + wlen[w]) of the packed z
+// and owns the compact range starting at coff[w] in every decoder buffer.  (Normal call: the windows ARE the
+// utterances and zoff == coff == offF.)  d_win = device ints {zoff[nw], coff[nw], wlen[nw]}.
+// (zoff0 = frame offset of window 0 inside z: the by-value form of a single window)
+int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
+    RUN_ALIASES(c)
     stage_begin(3);
-    int* const d_win = bt.meta_i + 5 * B + 2;
-    // (zoff0 = frame offset of window 0 inside z: the by-value form of a single window)
-    auto decode = [&](int nw, long Wtot, int maxW, int zoff0) -> int {
     const bool winl = nw == 1 && !no_inline_seg;
     auto lvF = [&](int scale, int extra) {
         Lvl l; l.seg = winl ? SegView{nullptr, nullptr, scale, extra, 0, maxW} : SegView{d_win + nw, d_win + 2 * nw, scale, extra, 0, 0};
@@ -1033,12 +1102,38 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     mark(4);
     if (wave) tap("wave", wave, 1, Ntot, Ntot);
     return STS_OK;
-    };   // decode
+}
 
+int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss) {
+    Model& M = model;
+    if (B <= 0 || !ids || !n) return fail(STS_EINVAL, "empty batch");
+    if (ss && (B != 1 || ss->chunk_frames <= 0 || !ss->cb)) return fail(STS_EINVAL, "streaming takes one utterance, a positive chunk size and a callback");
+    HIPCK(hipSetDevice(device));
+    taps.clear();
+    memset(&prof, 0, sizeof(prof));
+    for (double& f : flops_) f = 0;
+    for (double& f : bytes_) f = 0;
+    mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+
+    RunCtx c;
+    c.B = B; c.ids = ids; c.n = n; c.sid = sid; c.ls = ls; c.ss = ss;
+    int rc;
+    if ((rc = run_setup(c)) != STS_OK) return rc;
+    mark(0);
+    if ((rc = run_text_encoder(c)) != STS_OK) return rc;
+    if ((rc = run_durations(c)) != STS_OK) return rc;
+    if ((rc = run_frame_workspace(c)) != STS_OK) return rc;
+    if ((rc = run_flow(c)) != STS_OK) return rc;
+    return run_output(c);
+}
+
+// ---- stage 6: decode (one pass, or chunk by chunk when streaming), PCM to the host, profile
+int Engine::run_output(RunCtx& c) {
+    RUN_ALIASES(c)
     n_samples.resize(B);
     for (int b = 0; b < B; b++) n_samples[b] = p_lenF[b] * hop;
     if (!ss) {
-        const int rc = decode(B, Ftot, maxF, 0);   // windows = utterances (uploaded with the frame geometry)
+        const int rc = run_decode(c, B, Ftot, maxF, 0);   // windows = utterances (uploaded with the frame geometry)
         if (rc != STS_OK) return rc;
         d_pcm = bf.pcm;
         total_samples = Ftot * hop;
@@ -1057,7 +1152,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         int16_t* hp = nullptr;
         const size_t hp_off = (up_bytes + ((size_t)Ttot + B) * 4 + 255) & ~(size_t)255;
         if (!ensure_pinned(hp_off + (size_t)ss->chunk_frames * hop * 2 + 256)) return fail(STS_EDEVICE, "pinned host allocation failed");
-        pm = (int*)pinned_;
+        int* pm = c.pm = (int*)pinned_;
         hp = (int16_t*)(pinned_ + hp_off);
         int* pw = pm + 5 * B + 2;
         d_pcm = nullptr; total_samples = 0;
@@ -1066,7 +1161,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
             const long w0 = std::max<long>(0, f0 - halo), w1 = std::min<long>(F, f1 + halo);
             pw[0] = (int)w0; pw[1] = 0; pw[2] = (int)(w1 - w0);
             HIPCK(hipMemcpyAsync(d_win, pw, 3 * 4, hipMemcpyHostToDevice, stream));
-            const int rc = decode(1, w1 - w0, (int)(w1 - w0), (int)w0);
+            const int rc = run_decode(c, 1, w1 - w0, (int)(w1 - w0), (int)w0);
             if (rc != STS_OK) return rc;
             const long ns = (f1 - f0) * hop;
             HIPCK(hipMemcpyAsync(hp, bf.pcm + (f0 - w0) * hop, (size_t)ns * 2, hipMemcpyDeviceToHost, stream));

@@ -85,6 +85,14 @@ private:
     int pick_kslices(const DConv& c, const Lvl& lout) const;
     float* dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre = nullptr, const float* pre_in = nullptr,
                const float* pre_res = nullptr);
+    struct RunCtx;                  // what the stages of one run share (engine.hip)
+    int run_setup(RunCtx& c);
+    int run_text_encoder(RunCtx& c);
+    int run_durations(RunCtx& c);
+    int run_frame_workspace(RunCtx& c);
+    int run_flow(RunCtx& c);
+    int run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0);
+    int run_output(RunCtx& c);
     bool flow_program();            // builds (once) the op program of the persistent single-launch flow (persist.hip); false: not eligible
     void tap(const char* name, const float* d, int channels, long ld, long length);
     void stage_begin(int s);
