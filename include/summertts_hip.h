@@ -121,7 +121,8 @@ int sts_set_conv_math(sts_engine* e, int mode);
  *   workgroups on (default 96; 1 = always);  STS_DBG_FRONT_MODE -- the reverse flow of a one-utterance call:
  *   0 = automatic (today: one launch per layer), 1 = always one launch per layer, 2 = the persistent single-launch kernel of
  *   persist.hip (one window of the frame axis per XCD) whenever the model is eligible. */
-enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2, STS_DBG_PK_TRACE = 3 /* per-op timeline of the persistent kernel -> tap "pk_trace" */ };
+enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2, STS_DBG_PK_TRACE = 3 /* per-op timeline of the persistent kernel -> tap "pk_trace" */,
+       STS_DBG_TRUNK_MODE = 4 /* 128-channel decoder stage of a one-utterance call: 0 automatic, 1 grouped launches, 2 one persistent launch per stage */ };
 int sts_debug_set(sts_engine* e, int key, int value);
 
 /* Per-stage device timing of the last run, measured with HIP events on the engine's own stream. */

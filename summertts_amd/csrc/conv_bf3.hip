@@ -105,7 +105,7 @@ constexpr int kProdA[6] = {2, 0, 1, 1, 0, 0};
 constexpr int kProdB[6] = {0, 2, 1, 0, 1, 0};
 
 
-template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1>
+template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1, bool NTL = false>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b, const int pm = 0) {
     // pm (polyphase transposed convs): the workgroup's MT rows run over the MERGED row space phase * Cout_pad + row, so that
     // several phases (or all row blocks of a phase) share ONE staged, split input window instead of staging it once each
@@ -235,7 +235,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
                 const rsrc_t rs = make_rsrc(xbase + (size_t)(c * NSUB + isub[i]) * CK * x_ld + in_base, (unsigned)((15ul * x_ld + in_len) * 4ul));
 #pragma unroll
                 for (int e = 0; e < 8; e++)
-                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)xoff[i], (int)((unsigned)e * ld4), 0));
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)xoff[i], (int)((unsigned)e * ld4), NTL ? 2 : 0));
             }
     };
     auto store_tile = [&](int bufi) {
@@ -363,7 +363,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     }
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
     TT_STAMP(2);
-    if (wvalid) tile_epilogue<MW, NW>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
+    if (wvalid) tile_epilogue<MW, NW, NTL>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
 #ifdef STS_TILE_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores have left
     TT_STAMP(3);
@@ -678,6 +678,67 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent decoder-stage kernel (kernels.hpp StageArgs).  512 workgroups (two per CU) of the 128 x 128 tile; a workgroup serves
+// the XCD it runs on.  Item t of an XCD = ((op * ncol + column) * nmem + chain): claimed in this order through an L2 atomic, so every
+// item's dependencies -- the three column tiles around it of the previous op of the same chain -- were claimed earlier by
+// workgroups that never wait for a later item: no deadlock, whatever else runs on the device.  Coherence as in persist.hip:
+// in-kernel data is read with non-temporal loads (NTL body), a wave waits for its stores before the workgroup barrier that
+// precedes the completion flag, flags are relaxed agent-scope atomics in the XCD's L2.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_stage_kernel(StageArgs A) {
+    __shared__ int s_item;
+    const int tid = threadIdx.x;
+    const int x = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u);
+    const int ncol = A.ncol[x], nmem = A.nmem, nops = A.nops;
+    const int total = nops * ncol * nmem;
+    const size_t per_xcd = (size_t)1 + (size_t)nops * nmem * PS_MAX_COLS;
+    unsigned* claim = A.ctr + (size_t)x * per_xcd;
+    unsigned* done = claim + 1;
+    unsigned next = 0;
+    if (tid == 0) next = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (tid == 0) s_item = (int)next;
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(s_item);
+        if (t >= total) break;
+        if (tid == 0) next = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next item: its round trip rides under this tile
+        const int op = t / (ncol * nmem), rem = t - op * ncol * nmem;
+        const int col = rem / nmem, m = rem - col * nmem;
+        if (op > 0 && tid == 0) {
+            const unsigned* f = done + ((size_t)(op - 1) * nmem + m) * PS_MAX_COLS;
+            for (int c = col - 1; c <= col + 1; c++)
+                if (c >= 0 && c < ncol)
+                    while (__hip_atomic_load(f + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+#ifndef STS_STAGE_NTL
+#define STS_STAGE_NTL true
+#endif
+        // the conv's descriptor word by word through readfirstlane: every field in scalar registers (loaded through a pointer the
+        // compiler would treat them as divergent and wrap each buffer load in a waterfall loop: 22 per K step, measured 1.9x slower)
+        ConvArgs al;
+        {
+            const int* src = (const int*)&A.tab[((size_t)x * nops + op) * nmem + m];
+            int* dstw = (int*)&al;
+            static_assert(sizeof(ConvArgs) % 4 == 0, "ConvArgs is copied in 32-bit words");
+#pragma unroll
+            for (int w = 0; w < (int)(sizeof(ConvArgs) / 4); w++) dstw[w] = __builtin_amdgcn_readfirstlane(src[w]);
+        }
+        conv_bf3_body<2, 2, 2, 2, 1, 1, STS_STAGE_NTL>(al, 1, col, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have reached the L2
+        __syncthreads();                                           // ... and everybody's; the staged LDS window is free again
+        if (tid == 0) __hip_atomic_store(done + ((size_t)op * nmem + m) * PS_MAX_COLS + col, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the last workgroup to leave re-arms the counters for the next launch
+    __syncthreads();
+    unsigned* exitc = A.ctr + 8 * per_xcd;
+    if (tid == 0) s_item = __hip_atomic_fetch_add(exitc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (s_item)
+        for (size_t i = tid; i <= 8 * per_xcd; i += 256) __hip_atomic_store(A.ctr + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static inline void split_host(float x, uint16_t (&p)[3]) {
@@ -787,6 +848,16 @@ static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
 
 // 20: 128 x 128 with K split over two wave groups inside the workgroup (8 waves, 32-channel staged chunks)
 // 24: 256 x 64, K split over two wave groups (8 waves): all rows of a 256-channel conv behind ONE staged window
+size_t ps_counter_bytes(int nops, int nmem) { return ((size_t)8 * (1 + (size_t)nops * nmem * PS_MAX_COLS) + 16) * sizeof(unsigned); }
+// the stage kernel is instantiated for the plain 128 x 128 tile: one 128-row tile, 16-channel staged chunks, a plain (non-polyphase) conv
+bool conv_bf3_stage_eligible(const ConvArgs& a) {
+    return conv_bf3_eligible(a) && !a.transposed && a.Cout_pad == 128 && a.out_stride == 1 && (a.epi == EPI_STORE || a.epi == EPI_RESADD) && !a.ubias;
+}
+void conv_bf3_stage(const StageArgs& A, hipStream_t st) {
+    const size_t lds = bf3_lds_bytes<2, 2, 2, 2, 1, 1>();
+    hipLaunchKernelGGL(conv_bf3_stage_kernel, dim3(512), dim3(256), lds, st, A);
+}
+
 long conv_bf3_blocks(const ConvArgs& a) {
     const int nphase = a.transposed ? a.out_stride : 1;
     const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);

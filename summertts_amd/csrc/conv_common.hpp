@@ -114,11 +114,13 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 16
 // take a branch-free path: a row tile's 16 bias values and a column tile's 16 residual values are requested together
 // and waited for once.  (Measured: with the per-element epilogue switch each of a lane's 64 outputs paid its own dependent
 // bias load -- ~31 us of a 57 us tile for a 3-tap 128-channel conv.)
-template <int MW, int NW>
+// NTL: the residual is read with non-temporal loads (persistent stage kernel: it was written by another CU of this XCD inside
+// the same launch, a plain load could hit a stale line of this CU's vector L1)
+template <int MW, int NW, bool NTL = false>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[MW][NW], const int mbase, const int ncol0, const int l31,
                                              const int half, const int n_count, const int out_len, const size_t out_base, const int phase, const int b) {
     const int out_off = a.out_off + phase;
-    if ((a.epi == EPI_STORE || a.epi == EPI_RESADD) && a.out_stride == 1 && out_off == 0) {
+    if ((a.epi == EPI_STORE || a.epi == EPI_RESADD) && a.out_stride == 1) {
         // Plain convs (every ResBlock conv of the trunk).  Round 3 (tools/tile_trace.py): with one dword store and one dword residual
         // load per accumulator register the epilogue of a 128 x 128 tile took 16-24 us -- store-ISSUE-bound, 25-45 % of a tile's
         // life.  A lane's 4 registers of a row group are 4 consecutive ROWS of one column; after a 4 x 4 transpose inside the lane
@@ -139,16 +141,20 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             static_for<0, NW>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 const int n = ncol0 + q * 32 + m4;
-                const bool full = n + 3 < n_count && n + 3 < out_len;
+                const int pos = n + out_off;            // output position of column n (out_off != 0: a window that keeps only part of its columns)
+                const int klo = a.keep_hi > 0 ? a.keep_lo : 0, khi = a.keep_hi > 0 ? a.keep_hi : 0x7fffffff;
+                const bool full = n + 3 < n_count && pos >= 0 && pos + 3 < out_len && n >= klo && n + 3 < khi;
+                auto ok = [&](int e) { return n + e < n_count && pos + e >= 0 && pos + e < out_len && n + e >= klo && n + e < khi; };
+                const bool any = n < n_count && pos + 3 >= 0 && pos < out_len && n + 3 >= klo && n < khi;
                 f32x4u rv[4];
                 if (a.epi == EPI_RESADD) {
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         rv[g] = f32x4u{0.f, 0.f, 0.f, 0.f};
-                        if (rows_ok && rowv[g] < a.Cout && n < n_count) {
-                            const float* rp = a.res + (size_t)rowv[g] * a.res_ld + out_base + n;
-                            if (full) rv[g] = *(const f32x4u*)rp;
-                            else { for (int e = 0; e < 4; e++) if (n + e < n_count && n + e < out_len) rv[g][e] = rp[e]; }
+                        if (rows_ok && rowv[g] < a.Cout && any) {
+                            const float* rp = a.res + (size_t)rowv[g] * a.res_ld + out_base + pos;
+                            if (full) rv[g] = NTL ? __builtin_nontemporal_load((const f32x4u*)rp) : *(const f32x4u*)rp;
+                            else { for (int e = 0; e < 4; e++) if (ok(e)) rv[g][e] = NTL ? __builtin_nontemporal_load(rp + e) : rp[e]; }
                         }
                     }
                 }
@@ -156,16 +162,16 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 for (int g = 0; g < 4; g++) {
                     float w[4] = {acc[i][q][4 * g], acc[i][q][4 * g + 1], acc[i][q][4 * g + 2], acc[i][q][4 * g + 3]};
                     quad_transpose(w, l31);
-                    if (rows_ok && rowv[g] < a.Cout && n < n_count) {
+                    if (rows_ok && rowv[g] < a.Cout && any) {
                         f32x4u o;
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             const float r = a.epi == EPI_RESADD ? rv[g][e] : 0.f;
                             o[e] = a.ubias ? ((w[e] + bv[g]) + uv[g]) + r : (w[e] + bv[g]) + r;
                         }
-                        float* yp = a.y + (size_t)rowv[g] * a.y_ld + out_base + n;
+                        float* yp = a.y + (size_t)rowv[g] * a.y_ld + out_base + pos;
                         if (full) *(f32x4u*)yp = o;
-                        else { for (int e = 0; e < 4; e++) if (n + e < n_count && n + e < out_len) yp[e] = o[e]; }
+                        else { for (int e = 0; e < 4; e++) if (ok(e)) yp[e] = o[e]; }
                     }
                 }
             });

@@ -31,6 +31,10 @@ Engine::~Engine() {
     if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
     if (hmap_) (void)hipHostFree(hmap_);
     if (arrive_) (void)hipFree(arrive_);
+    if (ps_priv_) (void)hipFree(ps_priv_);
+    if (ps_tab_) (void)hipFree(ps_tab_);
+    if (ps_tab_host_) (void)hipHostFree(ps_tab_host_);
+    if (ps_ctr_) (void)hipFree(ps_ctr_);
     if (pk_prog_) (void)hipFree(pk_prog_);
     if (pk_ctr_) (void)hipFree(pk_ctr_);
     if (have_events_) {
@@ -846,6 +850,124 @@ int Engine::run_flow(RunCtx& c) {
     return STS_OK;
 }
 
+// One decoder stage of one utterance as ONE persistent launch (conv_bf3_stage, kernels.hpp StageArgs): the time axis cut into a
+// window per XCD (own column tiles + one tile of halo per side), private per-XCD buffers for the chain intermediates, the stage's
+// final chain outputs written (own columns only) where the grouped launches would have put them.  Returns false when the stage is
+// not eligible -- the caller then issues the grouped launches.  /root/reference/src/modules/ResBlock1.cpp:55-69.
+bool Engine::stage_persistent(RunCtx& c, int i, const float* bup, const Lvl& l2, float* reg, size_t ce, const float** outs) {
+    (void)c;
+    Model& M = model;
+    const int nk = M.n_resk;
+    const int nd = nk > 0 ? (int)M.rb[(size_t)i * nk].c1.size() : 0;
+    const int Cst = M.ups[i].Cout;
+    if (l2.nb != 1 || nk < 1 || nk > kMaxGroup || nd < 1 || Cst != 128) return false;
+    for (int j = 0; j < nk; j++) {       // one 128-column tile of halo per side must cover the receptive field of the whole chain
+        const DResBlock& rb = M.rb[(size_t)i * nk + j];
+        int r = 0;
+        for (int d = 0; d < nd; d++) r += rb.c1[d].dil * (rb.c1[d].k - 1) / 2 + rb.c2[d].dil * (rb.c2[d].k - 1) / 2;
+        if (r > 128 || (int)rb.c2.size() != nd) return false;
+    }
+    const long L = l2.total;
+    const int ntile = (int)((L + 127) / 128);
+    if (ntile < 8 * 3 || ntile / 8 + 3 > PS_MAX_COLS) return false;
+    const int nops = 2 * nd;
+    // windows: XCD x owns column tiles [t0, t1), computes [t0 - 1, t1 + 1) clipped
+    int own0[8], own1[8], win0[8], win1[8], ncol[8], maxw = 0;
+    for (int x = 0; x < 8; x++) {
+        own0[x] = (int)((long)ntile * x / 8); own1[x] = (int)((long)ntile * (x + 1) / 8);
+        win0[x] = own0[x] > 0 ? own0[x] - 1 : 0; win1[x] = own1[x] < ntile ? own1[x] + 1 : ntile;
+        ncol[x] = win1[x] - win0[x];
+        if (ncol[x] > maxw) maxw = ncol[x];
+    }
+    const long Wx = (long)maxw * 128;
+    const size_t need = (size_t)8 * nk * 3 * Cst * Wx;
+    if (need > ps_priv_cap_) {
+        (void)hipStreamSynchronize(stream);
+        if (ps_priv_) (void)hipFree(ps_priv_);
+        ps_priv_ = nullptr; ps_priv_cap_ = 0;
+        if (hipMalloc((void**)&ps_priv_, (need + need / 8) * sizeof(float)) != hipSuccess) return false;
+        ps_priv_cap_ = need + need / 8;
+    }
+    const size_t ntab = (size_t)8 * nops * nk;
+    if (ntab > ps_tab_cap_) {
+        (void)hipStreamSynchronize(stream);
+        if (ps_tab_) (void)hipFree(ps_tab_);
+        if (ps_tab_host_) (void)hipHostFree(ps_tab_host_);
+        ps_tab_ = nullptr; ps_tab_host_ = nullptr; ps_tab_cap_ = 0;
+        if (hipMalloc((void**)&ps_tab_, ntab * sizeof(ConvArgs)) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&ps_tab_host_, ntab * sizeof(ConvArgs), hipHostMallocDefault) != hipSuccess) return false;
+        ps_tab_cap_ = ntab;
+    }
+    const size_t cb = ps_counter_bytes(nops, nk);
+    if (cb > ps_ctr_cap_) {
+        (void)hipStreamSynchronize(stream);
+        if (ps_ctr_) (void)hipFree(ps_ctr_);
+        ps_ctr_ = nullptr; ps_ctr_cap_ = 0;
+        if (hipMalloc((void**)&ps_ctr_, cb) != hipSuccess) return false;
+        if (hipMemset(ps_ctr_, 0, cb) != hipSuccess) return false;
+        ps_ctr_cap_ = cb;
+    }
+    // members ordered longest K first (as the grouped launches order them)
+    int order[kMaxGroup];
+    for (int j = 0; j < nk; j++) order[j] = j;
+    for (int a2 = 1; a2 < nk; a2++)
+        for (int b2 = a2; b2 > 0 && M.rb[(size_t)i * nk + order[b2]].c1[0].k > M.rb[(size_t)i * nk + order[b2 - 1]].c1[0].k; b2--) { const int t = order[b2]; order[b2] = order[b2 - 1]; order[b2 - 1] = t; }
+    const double f0 = flops_[3], b0 = bytes_[3];
+    bool ok = true;
+    for (int x = 0; x < 8 && ok; x++) {
+        const long wlo = (long)win0[x] * 128, whi = std::min<long>(L, (long)win1[x] * 128);
+        const int Wlen = (int)(whi - wlo);
+        Lvl lw; lw.seg = SegView{nullptr, nullptr, 1, 0, 0, Wlen}; lw.nb = 1; lw.max_len = Wlen; lw.total = Wlen; lw.ld = Wx;     // private window
+        Lvl ls = lw; ls.ld = l2.ld;                                                                                           // window of a shared buffer
+        for (int mi = 0; mi < nk && ok; mi++) {
+            const int j = order[mi];
+            const DResBlock& rb = M.rb[(size_t)i * nk + j];
+            float* pt1 = ps_priv_ + ((size_t)(x * nk + j) * 3 + 0) * Cst * Wx;
+            float* ppa = pt1 + (size_t)Cst * Wx, *ppb = ppa + (size_t)Cst * Wx;
+            float* shared_out = reg + (size_t)(1 + 3 * j) * ce + ce;          // where the grouped path leaves chain j's result when nd is odd/even: see below
+            const float* cur = bup + wlo; bool cur_shared = true;
+            float* nxt_priv = ppa;
+            for (int d = 0; d < nd && ok; d++) {
+                const bool last = d + 1 == nd;
+                ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
+                ConvArgs a1 = conv_args(rb.c1[d], cur, cur_shared ? ls : lw, pt1, lw, o1, nullptr);
+                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur; o2.epi = EPI_RESADD; o2.res_ld = cur_shared ? l2.ld : Wx;
+                float* dst = last ? (shared_out + wlo) : nxt_priv;
+                ConvArgs a2 = conv_args(rb.c2[d], pt1, lw, dst, last ? ls : lw, o2, nullptr);
+                if (last) { a2.keep_lo = (int)((long)own0[x] * 128 - wlo); a2.keep_hi = (int)(std::min<long>(L, (long)own1[x] * 128) - wlo); }
+                ok = conv_bf3_stage_eligible(a1) && conv_bf3_stage_eligible(a2);
+                ps_tab_host_[((size_t)x * nops + 2 * d) * nk + mi] = a1;
+                ps_tab_host_[((size_t)x * nops + 2 * d + 1) * nk + mi] = a2;
+                cur = nxt_priv; cur_shared = false;
+                nxt_priv = nxt_priv == ppa ? ppb : ppa;
+            }
+            outs[j] = shared_out;
+        }
+    }
+    flops_[3] = f0; bytes_[3] = b0;        // (the table's conv_args calls booked 8 windows: undone; the stage is booked once below)
+    if (!ok) return false;
+    {   // FLOPs / algorithmic bytes exactly as the grouped launches book them
+        double fl = 0, f = 0;
+        for (int j = 0; j < nk; j++) {
+            const DResBlock& rb = M.rb[(size_t)i * nk + j];
+            for (int d = 0; d < nd; d++) {
+                ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
+                (void)conv_args(rb.c1[d], bup, l2, reg, l2, o1, &f); fl += f;
+                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = bup; o2.epi = EPI_RESADD;
+                (void)conv_args(rb.c2[d], bup, l2, reg, l2, o2, &f); fl += f;
+            }
+        }
+        mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_ += 1;
+    }
+    if (hipMemcpyAsync(ps_tab_, ps_tab_host_, ntab * sizeof(ConvArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+    StageArgs A;
+    memset(&A, 0, sizeof(A));
+    A.tab = ps_tab_; A.nops = nops; A.nmem = nk; A.ctr = ps_ctr_;
+    for (int x = 0; x < 8; x++) A.ncol[x] = ncol[x];
+    conv_bf3_stage(A, stream);
+    return true;
+}
+
 // ---- stage 5: one decode pass over `nw` windows of z
 // ---------------- decoder trunk (Generator_hifigan.cpp:139-175 and the identical loops of MS/Istft/MBB)
 // One decode pass over `nw` windows of z.  Window w covers frames [zoff[w], zoff[w] + wlen[w]) of the packed z
@@ -902,7 +1024,9 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
             flops_[3] = f0; bytes_[3] = b0;
             grouped = conv_group_eligible(G);
         }
-        if (grouped) {
+        if (grouped && trunk_mode == 2 && conv_math == 0 && nw == 1 && stage_persistent(c, i, bup, l2, reg, ce, outs)) {
+            // (the whole stage went out as one persistent launch)
+        } else if (grouped) {
             // Layer d of ALL chains goes out as one grouped launch: 2 * nd launches per stage instead of
             // 2 * nd * nResK, nResK times the workgroups per launch (a batch-1 stage otherwise yields only a
             // few hundred), and chains of different kernel size backfill each other inside the grid.

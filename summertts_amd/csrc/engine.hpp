@@ -72,6 +72,7 @@ public:
     int conv_math = 0;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA (sts_set_conv_math)
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
     bool pk_trace = false;             // record the persistent kernel's per-op timeline into taps["pk_trace"] (sts_debug_set)
+    int trunk_mode = 0;                // 0 automatic (today: grouped launches), 1 grouped launches, 2 persistent stage kernel where eligible (sts_debug_set)
     int front_mode = 0;                // 0 automatic, 1 one launch per layer, 2 persistent single-XCD kernel wherever eligible (sts_debug_set)
     hipStream_t stream = nullptr;
 
@@ -104,6 +105,10 @@ private:
     char* pinned_pcm_ = nullptr; size_t pinned_pcm_cap_ = 0;
     int* hmap_ = nullptr; int* hmap_dev_ = nullptr; size_t hmap_cap_ = 0;   // host-mapped result block of the durations kernel
     unsigned* arrive_ = nullptr; int seq_ = 0;
+    // persistent decoder-stage kernel (conv_bf3_stage): per-XCD private stage buffers, the conv table and its counters
+    float* ps_priv_ = nullptr; size_t ps_priv_cap_ = 0; ConvArgs* ps_tab_ = nullptr; ConvArgs* ps_tab_host_ = nullptr; size_t ps_tab_cap_ = 0;
+    unsigned* ps_ctr_ = nullptr; size_t ps_ctr_cap_ = 0;
+    bool stage_persistent(RunCtx& c, int stage, const float* bup, const Lvl& l2, float* reg, size_t ce, const float** outs);
     PkStep* pk_prog_ = nullptr; int pk_nsteps_ = 0, pk_halo_ = 0, pk_state_ = 0; unsigned* pk_ctr_ = nullptr;   // persistent flow kernel
     hipEvent_t ev_[8] = {};
     static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently

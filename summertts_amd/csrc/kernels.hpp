@@ -63,6 +63,9 @@ struct ConvArgs {
     // optional split-bf16 form of the same weights (conv_bf3.hip): every fp32 weight as three bf16 terms, fragment-packed by
     // bf3_pack(); null = this conv only has the fp32 matrix-core path
     const void* wb3;
+    // optional restriction of the OUTPUT to the columns n in [keep_lo, keep_hi) (keep_hi == 0: all): a window of the persistent
+    // stage kernel computes its halo columns but must not publish them (plain / residual epilogue of non-polyphase convs only)
+    int keep_lo, keep_hi;
 };
 
 // Segmented Winograd F(2,3): a k-tap filter is cut into n3 three-tap segments followed by n2 two-tap segments
@@ -160,6 +163,23 @@ struct PkFlowArgs {
 };
 size_t pk_counter_bytes();
 void pk_flow(const PkFlowArgs& A, hipStream_t st);
+
+// ---- persistent decoder-stage kernel (conv_bf3.hip, round 3): the 2 x nd grouped ResBlock convs of ONE decoder stage of ONE utterance
+// in one launch.  The time axis is cut into one window per XCD (own column tiles + one tile of halo per side, recomputed); inside
+// an XCD workgroups claim (op, column tile, chain) items in dependency order and wait on the completion flags of the three column
+// tiles of the previous op they read -- tiles of consecutive layers overlap, the chains balance dynamically, nothing drains
+// between the convs.  tab[(xcd * nops + op) * nmem + m]: the conv of op `op`, chain m, on XCD xcd's window (pointers already
+// offset to the window; private per-XCD buffers for everything but the stage's input and its final outputs).
+constexpr int PS_MAX_COLS = 512;
+struct StageArgs {
+    const ConvArgs* tab;
+    int nops, nmem;
+    int ncol[8];                    // column tiles (of 128) of each XCD's window
+    unsigned* ctr;                  // ps_counter_bytes() of zeroed device memory; the kernel re-arms it
+};
+size_t ps_counter_bytes(int nops, int nmem);
+bool conv_bf3_stage_eligible(const ConvArgs& a);
+void conv_bf3_stage(const StageArgs& A, hipStream_t st);
 
 // ---- launchers (all asynchronous on `st`) ------------------------------------------------------
 // Matrix-core (v_mfma_f32_32x32x2_f32) implicit-GEMM conv.  Returns false when the shape is not

@@ -806,3 +806,25 @@ def test_persistent_flow_kernels_of_several_engines_do_not_deadlock():
         assert np.array_equal(out[k], want)
     for e in engines:
         e.close()
+
+
+def test_persistent_decoder_stage_kernel_matches_the_grouped_launches():
+    """conv_bf3_stage: the six grouped convs of the 128-channel decoder stage of one utterance as ONE persistent launch (time axis
+    cut into a window per XCD with one tile of recomputed halo, tile-level dependencies inside an XCD) against the grouped
+    launches: every output value is accumulated in the same order, so the PCM must be identical; twice (counters re-arm)."""
+    cfg = sb.full_cfg("hifigan_sdp")
+    blob = sb.make_blob(cfg, 1234)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    for T in (128, 37, 300):
+        ids = sb.synthetic_ids(T, cfg.vocab, salt=T)
+        out = {}
+        for mode in (1, 2, 2):
+            syn.debug_set("trunk_mode", mode)
+            syn.run_batch([ids])
+            out.setdefault(mode, []).append((syn.pcm_host().copy(), syn.tap("wave")[0].copy()))
+        for pcm, wave in out[2]:
+            assert np.abs(wave - out[1][0][1]).max() <= 1e-6, (T, np.abs(wave - out[1][0][1]).max())
+            assert_pcm_close(pcm, out[1][0][0], f"T={T}: persistent stage vs grouped launches")
+        assert np.array_equal(out[2][0][0], out[2][1][0]), "persistent stage kernel is not deterministic"
+    syn.close()

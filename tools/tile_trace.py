@@ -23,6 +23,8 @@ blob = sb.make_blob(cfg, 1234)
 syn = engine.Synthesizer(blob)
 lens = [128] if B == 1 else np.random.default_rng(1234).integers(64, 257, size=B).tolist()
 ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=u) for u, t in enumerate(lens)]
+if os.environ.get("TT_TRUNK_MODE"):
+    syn.debug_set("trunk_mode", int(os.environ["TT_TRUNK_MODE"]))
 for _ in range(3):
     syn.run_batch(ids)
 lib = syn.lib
