@@ -871,6 +871,8 @@ bool Engine::stage_persistent(RunCtx& c, int i, const float* bup, const Lvl& l2,
     const int ntile = (int)((L + 127) / 128);
     if (ntile < 8 * 3 || ntile / 8 + 3 > PS_MAX_COLS) return false;
     const int nops = 2 * nd;
+    if (nops * nk > 32) return false;      // PS_MAX_CONVS: descriptors of a stage kept in the kernel's LDS
+    if (ps_tab_busy_) { (void)hipStreamSynchronize(stream); ps_tab_busy_ = false; }     // an earlier stage of this run still owns the staging table
     // windows: XCD x owns column tiles [t0, t1), computes [t0 - 1, t1 + 1) clipped
     int own0[8], own1[8], win0[8], win1[8], ncol[8], maxw = 0;
     for (int x = 0; x < 8; x++) {
@@ -965,6 +967,7 @@ bool Engine::stage_persistent(RunCtx& c, int i, const float* bup, const Lvl& l2,
     A.tab = ps_tab_; A.nops = nops; A.nmem = nk; A.ctr = ps_ctr_;
     for (int x = 0; x < 8; x++) A.ncol[x] = ncol[x];
     conv_bf3_stage(A, stream);
+    ps_tab_busy_ = true;
     return true;
 }
 
@@ -1238,6 +1241,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     for (double& f : flops_) f = 0;
     for (double& f : bytes_) f = 0;
     mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+    ps_tab_busy_ = false;          // (the previous run ended with a stream synchronisation)
 
     RunCtx c;
     c.B = B; c.ids = ids; c.n = n; c.sid = sid; c.ls = ls; c.ss = ss;

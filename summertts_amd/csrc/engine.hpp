@@ -107,7 +107,7 @@ private:
     unsigned* arrive_ = nullptr; int seq_ = 0;
     // persistent decoder-stage kernel (conv_bf3_stage): per-XCD private stage buffers, the conv table and its counters
     float* ps_priv_ = nullptr; size_t ps_priv_cap_ = 0; ConvArgs* ps_tab_ = nullptr; ConvArgs* ps_tab_host_ = nullptr; size_t ps_tab_cap_ = 0;
-    unsigned* ps_ctr_ = nullptr; size_t ps_ctr_cap_ = 0;
+    unsigned* ps_ctr_ = nullptr; size_t ps_ctr_cap_ = 0; bool ps_tab_busy_ = false;
     bool stage_persistent(RunCtx& c, int stage, const float* bup, const Lvl& l2, float* reg, size_t ce, const float** outs);
     PkStep* pk_prog_ = nullptr; int pk_nsteps_ = 0, pk_halo_ = 0, pk_state_ = 0; unsigned* pk_ctr_ = nullptr;   // persistent flow kernel
     hipEvent_t ev_[8] = {};
