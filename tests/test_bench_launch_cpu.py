@@ -49,3 +49,16 @@ def test_uneven_shards_with_an_empty_rank():
     # 3 ranks, batch such that one rank may hold fewer utterances: the gather must not hang
     out = _run(["--gpus", "3", "--steps", "2", "--warmup", "0", "--batch", "1", "--phonemes", "10"])
     assert out["n_gpus"] == 3 and sum(out["multi_gpu"]["samples_per_rank"]) == 2 * 3 * 1000
+
+
+def test_config_presets_name_the_baseline_config_they_form():
+    """`--config N` sets workload / batch / ragged for BASELINE.json's configs[N] and the line says which config it is;
+    ad-hoc flags that form no config are labelled custom (config.workload was hard-coded to configs[1])."""
+    out = _run(["--gpus", "2", "--config", "3", "--steps", "1", "--warmup", "0"])
+    assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 3 and out["config"]["workload"].startswith("configs[3]")
+    assert out["config"]["global_batch"] == 64 and sum(out["multi_gpu"]["utterances_per_rank"]) == 64
+    out = _run(["--gpus", "1", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": "29643"})
+    assert out["config"]["baseline_config"] == 1 and out["config"]["workload"].startswith("configs[1]")
+    out = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "5", "--phonemes", "33"],
+               {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": "29644"})
+    assert out["config"]["baseline_config"] is None and out["config"]["workload"].startswith("custom")
