@@ -204,7 +204,7 @@ def parity_report(ref_out, gpu_out):
     return rep
 
 
-def measured_mfma_ceiling():
+def measured_mfma_ceiling(products: int = BF16_PRODUCTS_PER_F32):
     """Runs tools/ubench/libsts_ubench.so (a bare loop of conv_bf3.hip's 24-MFMA sequence) in THIS process on operands with
     split-fp32 statistics and on constant operands: what the matrix pipe sustains on this box, now (data-dependent DVFS)."""
     import ctypes
@@ -220,7 +220,7 @@ def measured_mfma_ceiling():
         if split <= 0:
             return None
         return {"bf16_tflops_split_fp32_operands": split, "bf16_tflops_constant_operands": const,
-                "tflops_fp32_equivalent": split / BF16_PRODUCTS_PER_F32,
+                "tflops_fp32_equivalent": split / products,
                 "source": "tools/ubench/mfma_bf16_peak.hip run in this process right after the timed legs: 512 workgroups x 4 waves, "
                           "20 000 x 24 v_mfma_f32_32x32x16_bf16 per wave (~20 ms)"}
     except Exception:
@@ -240,7 +240,8 @@ def kernel_build_id() -> str:
 
 def _env_conv_math() -> str:
     """STS_CONV_MATH as the engine reads it (f32 / fp32 / 1 = exact-fp32 MFMA, anything else = split-bf16)."""
-    return "f32" if os.environ.get("STS_CONV_MATH", "") in ("f32", "fp32", "1") else "bf16x3"
+    v = os.environ.get("STS_CONV_MATH", "")
+    return "f32" if v in ("f32", "fp32", "1") else ("f16x2" if v in ("f16x2", "3") else "bf16x3")
 
 
 def main():
@@ -263,9 +264,10 @@ def main():
     ap.add_argument("--cpu-sample-phonemes", type=int, default=0, help="0 = the GPU step's utterance (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=0)
-    ap.add_argument("--conv-math", default=_env_conv_math(), choices=["bf16x3", "f32"],
+    ap.add_argument("--conv-math", default=_env_conv_math(), choices=["bf16x3", "f32", "f16x2"],
                     help="arithmetic of the decoder trunk convs: bf16x3 = fp32 operands split exactly into three bf16 terms, six bf16 "
-                         "MFMA products per fp32 product, fp32 accumulation (default, same parity tolerances); f32 = the exact-fp32 MFMA")
+                         "MFMA products per fp32 product, fp32 accumulation (default, same parity tolerances); f32 = the exact-fp32 MFMA; "
+                         "f16x2 = two fp16 terms, three fp16 MFMA products per fp32 product (same parity tolerances, half the matrix time)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed leg on the exact-fp32 MFMA path")
     ap.add_argument("--pipeline-engines", type=int, default=2,
                     help="extra (not the headline): throughput with this many engines fed by concurrent host threads, "
@@ -436,7 +438,7 @@ def main():
     # ---- second timed leg (rank 0, one GPU): the same step with the trunk convs on the exact-fp32 MFMA instruction, so that
     # the line carries both arithmetic paths measured in the same process
     f32_leg = None
-    if dist is None and not stub and args.conv_math == "bf16x3" and not args.no_f32_leg and hasattr(syn, "set_conv_math"):
+    if dist is None and not stub and args.conv_math in ("bf16x3", "f16x2") and not args.no_f32_leg and hasattr(syn, "set_conv_math"):
         syn.set_conv_math("f32")
         for _ in range(2):
             step()
@@ -461,8 +463,8 @@ def main():
                                 "frac": a2 / PEAK_F32_MFMA_TFLOPS, "mfma_issued_tflops": i2,
                                 "mfma_issued_frac": i2 / PEAK_F32_MFMA_TFLOPS}}
         gpu_out["f32"] = capture_output()
-        syn.set_conv_math("bf16x3")
-    ceiling = measured_mfma_ceiling() if (dist is None and not stub and rank == 0) else None
+        syn.set_conv_math(args.conv_math)
+    ceiling = measured_mfma_ceiling(3 if args.conv_math == "f16x2" else BF16_PRODUCTS_PER_F32) if (dist is None and not stub and rank == 0) else None
 
     # ---- extra figure (not the headline): the native request pool (sts_pool: N engines, one worker thread each,
     # one FIFO).  "pipelined" = batch-1 requests only overlapped across engines (max_batch 1); "burst" = the same
@@ -524,7 +526,8 @@ def main():
         issued_tf = (acc.get("flops_decoder_mfma_executed", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
         bf16_tf = (acc.get("flops_decoder_bf16_issued", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
         split = bf16_tf > 0.0                       # the trunk ran on split operands (conv_bf3.hip)
-        peak_tf = PEAK_BF16_MFMA_TFLOPS / BF16_PRODUCTS_PER_F32 if split else PEAK_F32_MFMA_TFLOPS
+        products = 3 if args.conv_math == "f16x2" else BF16_PRODUCTS_PER_F32      # 16-bit matrix products per fp32 product
+        peak_tf = PEAK_BF16_MFMA_TFLOPS / products if split else PEAK_F32_MFMA_TFLOPS
         # per-stage rooflines of the part of the step that is NOT the matrix-core decoder: bound = max(bytes / HBM peak, flops / MFMA peak)
         stages = {}
         for name, kms, kfl, kby in (("text_encoder", "ms_text_encoder", "flops_text_encoder", "bytes_text_encoder"),
@@ -555,8 +558,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (decoder trunk convs: fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, "
-                      "f32 accumulation; everything else f32)") if split else "f32",
+            "dtype": (("f32 (decoder trunk convs: fp32 operands as 2 fp16 terms, 3 fp16 MFMA products per fp32 product, f32 accumulation; "
+                       "everything else f32)") if args.conv_math == "f16x2" else
+                      ("f32 (decoder trunk convs: fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, "
+                       "f32 accumulation; everything else f32)")) if split else "f32",
             "data": "synthetic (seeded random weights in the reference .bin grammar; ids[i]=(i*37+11) mod vocab); the reference's "
                     "real .bin models are absent from /root/reference, every number here is on synthetic weights",
             "config": {
@@ -573,7 +578,7 @@ def main():
             "host_sync_wait_ms_per_step": acc.get("ms_sync_wait_host", 0.0) / steps,
             "roofline": {
                 "kernel": ("conv_bf3_kernel + conv_bf3_group_kernel + resblock_bf3_kernel (decoder upsamplers + grouped / fused ResBlock convs, "
-                           "v_mfma_f32_32x32x16_bf16 on split operands)") if split else
+                           + ("v_mfma_f32_32x32x16_f16 on two-term operands)" if args.conv_math == "f16x2" else "v_mfma_f32_32x32x16_bf16 on split operands)")) if split else
                           ("conv_mfma_kernel + conv_mfma_group_kernel + resblock_wino_kernel / resblock_layer_kernel (decoder upsamplers + "
                            "grouped / fused ResBlock convs, v_mfma_f32_32x32x2_f32)"),
                 "bound": "mfma",
@@ -581,20 +586,20 @@ def main():
                 "peak": peak_tf,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / peak_tf,
-                "peak_definition": (f"bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF/s / {BF16_PRODUCTS_PER_F32} bf16 products per fp32 product "
+                "peak_definition": (f"bf16 / fp16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF/s / {products} 16-bit products per fp32 product "
                                     "(MI355X_MICROARCH.md; the exact-fp32 MFMA peak is 157.3)") if split else
                                    "v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)",
                 "traffic": traffic,
                 "achieved_definition": "ALGORITHMIC (direct-form, true-tap) fp32 FLOPs of the launches / their HIP-event time: the task's "
                                        "roofline figure (SURVEY.md 8d).  It is an effective rate, not pipe utilisation -- see *_issued_*",
                 "sustained_mfma_ceiling": (dict(ceiling, frac=achieved_tf / ceiling["tflops_fp32_equivalent"], measured=True) if ceiling else
-                                           {"tflops_fp32_equivalent": SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32,
-                                            "frac": achieved_tf / (SUSTAINED_BF16_SPLIT_TFLOPS / BF16_PRODUCTS_PER_F32), "measured": False,
+                                           {"tflops_fp32_equivalent": SUSTAINED_BF16_SPLIT_TFLOPS / products,
+                                            "frac": achieved_tf / (SUSTAINED_BF16_SPLIT_TFLOPS / products), "measured": False,
                                             "source": "tools/ubench/libsts_ubench.so not built: constant from profiles/r02_mfma_bf16_peak_ubench.log "
                                                       "(1712 bf16 TF/s of the nominal 2500)"}) if split else None,
                 "bf16_issued_tflops": bf16_tf,
                 "bf16_issued_frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
-                "bf16_issued_definition": "bf16 matrix-core FLOPs the split-operand launches issue (6 x their algorithmic FLOPs) / the same "
+                "bf16_issued_definition": "bf16 matrix-core FLOPs the split-operand launches issue (6 x their algorithmic FLOPs; 3 x under f16x2) / the same "
                                           "time, against the bf16 dense peak: <= 1 by construction",
                 "mfma_issued_tflops": issued_tf,
                 "mfma_issued_frac": issued_tf / PEAK_F32_MFMA_TFLOPS,

@@ -113,7 +113,11 @@ int sts_set_conv_mode(sts_engine* e, int mode);
  *   1 = the exact-fp32 MFMA instruction (v_mfma_f32_32x32x2_f32) everywhere;
  *   2 = as 0, and also for every other eligible matrix-core conv (flow, text encoder) regardless of its grid size -- by default
  *       those switch to the split form only from the batch size on at which they stop being launch-latency-bound (tests).
- *   The default can also be chosen with the environment variable STS_CONV_MATH = bf16x3 | f32. */
+ *   3 = "f16x2": fp32 operands as TWO fp16 terms (the small one pre-scaled by 2^11, weights by a per-conv power of two), three
+ *       fp16 MFMA products per fp32 product -- half the matrix-pipe time of 0, 22-23 instead of 24 operand bits (measured error
+ *       against float64: DESIGN.md 5f).  An activation beyond fp16's range raises a flag and the call is repeated in form 0
+ *       (sts_profile.conv_math_fallbacks counts these); streaming calls always use form 0.
+ *   The default can also be chosen with the environment variable STS_CONV_MATH = bf16x3 | f32 | f16x2. */
 int sts_set_conv_math(sts_engine* e, int mode);
 
 /*   test hooks (per engine, never read from the environment): force a kernel family that the automatic choice would not pick
@@ -139,13 +143,15 @@ typedef struct sts_profile {
     double bytes_text_encoder, bytes_duration, bytes_flow;   /* algorithmic HBM bytes per stage (as bytes_decoder_min) */
     float ms_sync_wait_host;        /* host time blocked on the frame-count download (the one data-dependent sync) */
     double flops_decoder_bf16_issued;     /* bf16 matrix-core FLOPs issued by the timed launches that run on split operands
-                                             (6 x their algorithmic FLOPs); 0 with sts_set_conv_math(1) */
+                                             (6 x their algorithmic FLOPs; 3 x with sts_set_conv_math(3)); 0 with sts_set_conv_math(1) */
+    int64_t conv_math_fallbacks;          /* sts_set_conv_math(3): calls of this engine so far that were repeated in the split-bf16 form */
 } sts_profile;
 int sts_set_profiling(sts_engine* e, int enable);
 int sts_get_profile(const sts_engine* e, sts_profile* p);
 
 /* Stand-alone conv entry for op-level parity tests: y = conv1d(x) with x [Cin][L] on the host.
- * w is the reference layout [out][k][in] (transposed: same).  mode as sts_set_conv_mode. */
+ * w is the reference layout [out][k][in] (transposed: same).  mode as sts_set_conv_mode; 13 / 20.. = the split-bf16 kernel
+ * (automatic tile / tile code mode - 20), 50 / 60.. = the two-term fp16 kernel (automatic tile / tile code mode - 60). */
 int sts_debug_conv1d(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias,
                      int32_t Cout, int32_t k, int32_t pad, int32_t dil, int32_t stride_transposed,
                      int32_t depthwise, float in_slope, int32_t in_act, int mode, float** y, int32_t* Lout);

@@ -140,7 +140,7 @@ int sts_set_forced_durations(sts_engine* e, const int32_t* dur, int64_t count) {
 int sts_set_record_taps(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.record_taps = enable != 0; return STS_OK; }
 int sts_set_conv_math(sts_engine* e, int mode) {
     if (!e) return set_err(STS_EINVAL, "null engine");
-    if (mode < 0 || mode > 2) return set_err(STS_EINVAL, "conv math: 0 = split-bf16 (default), 1 = exact fp32, 2 = split-bf16 wherever eligible");
+    if (mode < 0 || mode > 3) return set_err(STS_EINVAL, "conv math: 0 = split-bf16 (default), 1 = exact fp32, 2 = split-bf16 wherever eligible, 3 = two-term fp16");
     e->eng.conv_math = mode;
     return STS_OK;
 }
@@ -239,18 +239,21 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         wino_pack(w, (long)k * Cin, Cin, 1, Cout, k, Cin, Cin_pad, Cout_pad, wu.data());
     }
     // modes 13 / 20..25 / 28..33: the split-bf16 kernel (conv_bf3.hip), automatic tile / tile code (mode - 20)
+    const bool h2 = (mode == 50 || (mode >= 60 && mode < 85)) && !depthwise;       // the two-term fp16 form of the same kernel
+    if (h2) mode = mode == 50 ? 13 : mode - 40;
     const bool bf3 = (mode == 13 || (mode >= 20 && mode < 45)) && !depthwise;
     std::vector<unsigned char> wb3;
+    float h2_scale = 1.0f;
     if (bf3) {
-        wb3.resize(bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, nullptr));
-        bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, wb3.data());
+        wb3.resize(bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, nullptr, false, h2 ? 1 : 0));
+        bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, wb3.data(), false, h2 ? 1 : 0, &h2_scale);
     }
     void* dwb3 = nullptr;
     float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dwu = nullptr; int* dseg = nullptr;
     int seg[2] = {0, 1};
     bool ok = hipMalloc((void**)&dx, (size_t)Cin * L * 4) == hipSuccess && hipMalloc((void**)&dw, (wn + 1024) * 4) == hipSuccess &&
               hipMalloc((void**)&db, (size_t)Cout_pad * 4) == hipSuccess && hipMalloc((void**)&dy, (size_t)Cout * Lout * 4) == hipSuccess &&
-              hipMalloc((void**)&dseg, 8) == hipSuccess;
+              hipMalloc((void**)&dseg, 32) == hipSuccess;
     int rc = STS_OK;
     if (ok && !wu.empty()) ok = hipMalloc((void**)&dwu, (wu.size() + 1024) * 4) == hipSuccess;
     if (ok && bf3) ok = hipMalloc(&dwb3, wb3.size() + 4096) == hipSuccess;
@@ -259,6 +262,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         (void)hipMemcpy(dx, x, (size_t)Cin * L * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(dw, wp.data(), wn * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(db, bp.data(), (size_t)Cout_pad * 4, hipMemcpyHostToDevice);
+        (void)hipMemset(dseg, 0, 32);
         (void)hipMemcpy(dseg, seg, 8, hipMemcpyHostToDevice);
         (void)hipMemset(dy, 0, (size_t)Cout * Lout * 4);
         ConvArgs a;
@@ -273,6 +277,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         a.in_seg = SegView{dseg, dseg + 1, L, 0}; a.out_seg = SegView{dseg, dseg + 1, Lout, 0}; a.B = 1;
         if (dwu) { (void)hipMemcpy(dwu, wu.data(), wu.size() * 4, hipMemcpyHostToDevice); a.wu = dwu; a.wino_n3 = wn3; a.wino_n2 = wn2; }
         if (dwb3) { (void)hipMemcpy(dwb3, wb3.data(), wb3.size(), hipMemcpyHostToDevice); a.wb3 = dwb3; }
+        if (h2) { a.math = 1; a.wscale = h2_scale; a.ovf = (unsigned*)dseg + 4; }     // (overflow word: behind the segment table)
         auto launch = [&]() {
             if (bf3) conv_bf3(a, nullptr, mode == 13 ? -1 : mode - 20);
             else if (mode == 12) conv_wino(a, nullptr);

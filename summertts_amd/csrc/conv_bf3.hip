@@ -55,6 +55,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef STS_VAR
 #define STS_VAR 6
 #endif
+#ifndef STS_H2_AR
+#define STS_H2_AR 2         // ring of weight fragments of the two-term fp16 kernels' plain tiles: step s + STS_H2_AR - 1 is requested during step s
+#endif
+#ifndef STS_H2_WAVES
+#define STS_H2_WAVES 2      // most waves per SIMD the two-term fp16 kernels are compiled for (lab: VAR_TAG=w3 VAR_EXTRA=-DSTS_H2_WAVES=3 tools/var_build.sh 6:
+                            // 168 registers, three waves per SIMD -- no effect at one utterance, -0.8 % at 32)
+#endif
 
 #ifdef STS_TILE_TRACE
 // Lab build only (tools/var_build.sh with -DSTS_TILE_TRACE): every workgroup of the staged kernel appends one record
@@ -104,8 +111,66 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 constexpr int kProdA[6] = {2, 0, 1, 1, 0, 0};
 constexpr int kProdB[6] = {0, 2, 1, 0, 1, 0};
 
+// ------------------------------------------------------------------------------------------------
+// MATH 1 ("f16x2", round 3): the same kernels with every fp32 operand as TWO fp16 terms and THREE products per fp32 product --
+// half the matrix-pipe time of the split-bf16 form.  fp16 carries 11 significant bits, so hi + lo holds 22-23 of an fp32's 24;
+// what makes it usable is keeping the small term out of fp16's subnormal range:
+//   activation x:  hi = fp16(x),  lo' = fp16((x - hi) * 2^11)        (the residual is exact in fp32; scaled it is as large as x)
+//   weight     w:  ws = w * 2^s with max |ws| in [2^13, 2^14) per conv (bf3_pack math 1, host);  P0 = fp16(ws), P1 = fp16(ws - P0)
+//                  are packed (two planes: 2 KB per 32-row tile and step instead of 3 KB);  P2 = P0 * 2^-11 (exact above the
+//                  subnormals) costs the kernel one packed multiply per fragment dword -- a third less weight traffic out of L2
+//   x * ws  ~=  hi * P0  +  hi * P1  +  lo' * P2        (dropped: lo * lo, relative 2^-22 worst case, ~2^-24.6 rms)
+// every product is exact in the fp32 accumulator; the tile is multiplied by 2^-s before the epilogue.  |x| > 65504 does not fit
+// fp16: the staging code tracks max |x| and raises ConvArgs::ovf, the engine then repeats the utterance in the split-bf16 form.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kH2Limit = 60000.f;
+__device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& lo, float& amax) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const f32x2 v = {x[2 * d], x[2 * d + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);                 // round to nearest even
+        const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * 2048.f;
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[d] = __builtin_bit_cast(unsigned, h);
+        lo[d] = __builtin_bit_cast(unsigned, l);
+        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
+    }
+}
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// weight planes P2 / P1 / P0 against activation planes lo' / hi / hi, smallest term first
+constexpr int kProdAh[3] = {2, 1, 0};
+constexpr int kProdBh[3] = {1, 0, 0};
 
-template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1, bool NTL = false>
+// one (chunk, tap) step of a wave's tile in either arithmetic
+template <int MATH, int MW, int NW, int NPA, int NPB>
+__device__ __forceinline__ void step_mfmas(f32x16 (&acc)[MW][NW], const u32x4 (&ac)[MW][NPA], const u32x4 (&bc)[NW][NPB]) {
+    if constexpr (MATH == 0) {
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int i = 0; i < MW; i++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(ac[i][kProdA[p]], bc[q][kProdB[p]], acc[i][q]);
+    } else {
+        u32x4 p2[MW];                               // P2 = P0 * 2^-11
+#pragma unroll
+        for (int i = 0; i < MW; i++) p2[i] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, ac[i][0]) * (_Float16)0.00048828125f);
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int i = 0; i < MW; i++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) acc[i][q] = mfma_f16(p == 0 ? p2[i] : ac[i][kProdAh[p]], bc[q][kProdBh[p]], acc[i][q]);
+    }
+}
+
+
+template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1, bool NTL = false, int MATH = 0>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b, const int pm = 0) {
     // pm (polyphase transposed convs): the workgroup's MT rows run over the MERGED row space phase * Cout_pad + row, so that
     // several phases (or all row blocks of a phase) share ONE staged, split input window instead of staging it once each
@@ -120,7 +185,10 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     constexpr int NSLOT = WIN / 32;                    // staging slots of 32 positions x 16 channels (one wave-wide load group)
     constexpr int NITEM = NSLOT * NSUB;                // (sub-chunk, slot) items per staged chunk
     constexpr int SPW = (NITEM + NWAVE - 1) / NWAVE;   // items per wave
-    constexpr int PLANE = WIN * 32, SUB = 3 * PLANE, BUF = NSUB * SUB;   // bytes
+    constexpr int NPB = MATH ? 2 : 3;                  // planes of a staged activation
+    constexpr int NPA = MATH ? 2 : 3;                  // packed planes of a weight
+    constexpr unsigned ABLK = NPA * 1024u;             // bytes of one (step, 32-row tile) block of the packed weights
+    constexpr int PLANE = WIN * 32, SUB = NPB * PLANE, BUF = NSUB * SUB;   // bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 #ifdef STS_TILE_TRACE
     long long* tt_rec = nullptr;
@@ -180,29 +248,29 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     const int nrt = a.Cout_pad / 32;
 
     // ---- A fragments: step s = (16-channel chunk) * ntap + tap is one contiguous block of nrt * 3 KB
-    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps_all * nrt * 3072));
+    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps_all * nrt * ABLK));
     // (the wave's row tile goes into the per-lane offset: the compiler cannot prove tid >> 6 wave-uniform and would wrap
     // every load in a readfirstlane loop if it sat in the scalar offset)
-    const unsigned a_voff = wvalid ? (unsigned)lane * 16u + ((unsigned)phase * (unsigned)nsteps_all * (unsigned)nrt + (unsigned)(mbase >> 5)) * 3072u : kOOB;
+    const unsigned a_voff = wvalid ? (unsigned)lane * 16u + ((unsigned)phase * (unsigned)nsteps_all * (unsigned)nrt + (unsigned)(mbase >> 5)) * ABLK : kOOB;
     const unsigned a_s0 = 0u;
-    const unsigned a_step = (unsigned)nrt * 3072u;
-    auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
+    const unsigned a_step = (unsigned)nrt * ABLK;
+    auto load_a = [&](int s, u32x4 (&dst)[MW][NPA]) {
         const unsigned sb = a_s0 + (unsigned)s * a_step;
 #pragma unroll
         for (int i = 0; i < MW; i++)
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
-                dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
+            for (int pl = 0; pl < NPA; pl++)
+                dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)i * ABLK + (unsigned)(pl * 1024)), 0));
     };
     // ---- B fragments of (sub-chunk, tap j) out of the staged, split window
     const int b_t0 = wn * NW * 32 + l31 + a.tap_off - lo;
-    auto load_b = [&](int bufi, int sub, int j, u32x4 (&dst)[NW][3]) {
+    auto load_b = [&](int bufi, int sub, int j, u32x4 (&dst)[NW][NPB]) {
         const int t = b_t0 + j * a.tap_step;
         const unsigned char* sb = smem3 + bufi * BUF + sub * SUB + t * 32 + ((half ^ ((t >> 3) & 1)) << 4);
 #pragma unroll
         for (int q = 0; q < NW; q++)
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE + q * 1024);
+            for (int pl = 0; pl < NPB; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE + q * 1024);
     };
 
     // ---- input staging: wave w owns items w, w + NWAVE, ... of a chunk; item = (sub-chunk, slot); lane (l31, half) of an item
@@ -225,6 +293,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     float xr[SPW][8];
     int as = 0;        // next A step to request
     const float act_slope = a.in_act ? a.in_slope : 1.0f;
+    float amax = 0.f;  // MATH 1: largest staged magnitude this lane has seen
     auto load_x = [&](int c) {
         if ((STS_EXP & 1) && c > 0) return;
         // one descriptor per 16-channel sub-chunk, based at its first row: rows ride in the scalar offset, the per-lane
@@ -254,21 +323,28 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 #pragma unroll
                     for (int e = 0; e < 8; e++) { v[e] = xr[i][e]; if (a.in_act) v[e] = v[e] < 0.f ? v[e] * a.in_slope : v[e]; }
                 }
-                u32x4 ph, pm, pl;
-                split8(v, ph, pm, pl);
-                *(u32x4*)(sb + lds_w[i]) = ph;
-                *(u32x4*)(sb + PLANE + lds_w[i]) = pm;
-                *(u32x4*)(sb + 2 * PLANE + lds_w[i]) = pl;
+                if constexpr (MATH == 0) {
+                    u32x4 ph, pm, pl;
+                    split8(v, ph, pm, pl);
+                    *(u32x4*)(sb + lds_w[i]) = ph;
+                    *(u32x4*)(sb + PLANE + lds_w[i]) = pm;
+                    *(u32x4*)(sb + 2 * PLANE + lds_w[i]) = pl;
+                } else {
+                    u32x4 ph, pl;
+                    split8h(v, ph, pl, amax);
+                    *(u32x4*)(sb + lds_w[i]) = ph;
+                    *(u32x4*)(sb + PLANE + lds_w[i]) = pl;
+                }
             }
     };
 
     // ---- main loop over this wave's steps (chunk, sub-chunk, tap): A (L2) and B (LDS) fragments one step ahead
     // A ring: 2 = the fragments of step s + 1 are requested during step s; 3 (STS_VAR & 16, plain tiles only) = two steps ahead
-    constexpr int AR = ((STS_VAR & 16) && NSUB == 1 && KG == 1) ? 3 : 2;
-    u32x4 fa[AR][MW][3], fb[2][NW][3];
+    constexpr int AR = (NSUB == 1 && KG == 1) ? (MATH == 1 ? STS_H2_AR : ((STS_VAR & 16) ? 3 : 2)) : 2;
+    u32x4 fa[AR][MW][NPA], fb[2][NW][NPB];
     int sj = 0, ssub = kg, sc = 0;
     auto a_index = [&](int c, int sub, int j) { return (c * NSUB + sub) * a.ntap + j; };
-    auto do_step = [&](u32x4 (&acur)[MW][3], u32x4 (&anew)[MW][3], u32x4 (&bcur)[NW][3], u32x4 (&bnxt)[NW][3], int s) {
+    auto do_step = [&](u32x4 (&acur)[MW][NPA], u32x4 (&anew)[MW][NPA], u32x4 (&bcur)[NW][NPB], u32x4 (&bnxt)[NW][NPB], int s) {
         int nj = sj + 1, nsub = ssub, nc = sc;
         const bool late_a = (STS_VAR & 32) != 0;       // request the next step's weight fragments in the same block as the MFMAs
         int a_next;
@@ -290,13 +366,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         if (late_a) load_a(a_next, anew);
         if (!(STS_EXP & 16) || s < 2) load_b(nc & 1, nsub, nj, bnxt);   // past the last step: stale LDS inside the tile, never used
         if (!(STS_VAR & (1 | 32))) __builtin_amdgcn_sched_barrier(0);
-        if (!(STS_EXP & 64))
-#pragma unroll
-        for (int p = 0; p < 6; p++)
-#pragma unroll
-            for (int i = 0; i < MW; i++)
-#pragma unroll
-                for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(acur[i][kProdA[p]], bcur[q][kProdB[p]], acc[i][q]);
+        if (!(STS_EXP & 64)) step_mfmas<MATH, MW, NW, NPA, NPB>(acc, acur, bcur);
         if (STS_VAR & (8 | 32)) {
             // the step's 6 LDS reads and 6 weight loads spread between its MFMAs (2 MFMAs per memory operation)
 #pragma unroll
@@ -311,7 +381,8 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     };
     load_x(0);
     load_a(a_index(0, kg, 0), fa[0]);
-    if constexpr (AR == 3) load_a(1, fa[1]);
+    if constexpr (AR >= 3) load_a(1, fa[1]);
+    if constexpr (AR >= 4) load_a(2, fa[2]);
     store_tile(0);
     __syncthreads();
     TT_STAMP(1);
@@ -323,6 +394,16 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
             if (u < 2 || s + u < nsteps) { if (s + u < nsteps) do_step(fa[u % AR], fa[(u + AR - 1) % AR], fb[u % 2], fb[(u + 1) % 2], s + u); }
         });
 
+    if constexpr (MATH == 1) {
+        if (amax > kH2Limit && a.ovf) *a.ovf = 1u;      // a staged value does not fit fp16: the caller repeats the run in the split-bf16 form
+        const float ws = a.wscale;                      // 2^-s of the weight pack
+#pragma unroll
+        for (int i = 0; i < MW; i++)
+#pragma unroll
+            for (int j = 0; j < NW; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] *= ws;
+    }
     if constexpr (KG > 1) {
         // ---- exchange the partial tiles: group g gives away its sums for the column tiles it does not finish
         constexpr int REG = NTW * MW * (NW / KG) * 16 * 64;        // floats per owner region
@@ -370,16 +451,16 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 #endif
 }
 
-template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, int MATH = 0>
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
     const TileId t = map_tile(nx, ny, a.B);
     if (!t.valid) return;
-    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(a, mtiles, t.bx, t.by, t.bz, pm);
+    conv_bf3_body<MW, NW, WM, WN, NSUB, KG, false, MATH>(a, mtiles, t.bx, t.by, t.bz, pm);
 }
 
 // grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
-template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny, int interleave) {
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, int MATH = 0>
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny, int interleave) {
     const TileId t = map_tile(nx, ny, B * G.n);
     if (!t.valid) return;
     // interleave: consecutive dispatch units belong to different members (different K lengths), so that workgroups that
@@ -388,7 +469,7 @@ __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_e
     if (interleave) { const int unit = t.bz * nx + t.bx; gi = unit % G.n; const int rest = unit / G.n; bx = rest % nx; b = rest / nx; }
     else { gi = t.bz / B; bx = t.bx; b = t.bz - gi * B; }
     const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_bf3_body<MW, NW, WM, WN, NSUB, KG>(ga[gi], mtiles, bx, t.by, b);
+    conv_bf3_body<MW, NW, WM, WN, NSUB, KG, false, MATH>(ga[gi], mtiles, bx, t.by, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -402,10 +483,13 @@ __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_e
 // The intermediate is parked in the k order the accumulator layout gives for free (a lane holds rows 4 h + {0..3} and
 // 8 + 4 h + {0..3} of every 16-row block = one 16-byte unit per plane); conv2's weights are packed to match (perm_k).
 // ------------------------------------------------------------------------------------------------
-template <int MW, int WM, int NW, int WN>
+template <int MW, int WM, int NW, int WN, int MATH = 0>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock_bf3_kernel(ResLayerGroup G, int nx, int wst, int interleave) {
     constexpr int C = 32 * MW * WM, NCH = C / 16, NRT = C / 32, NWAVE = WM * WN, P1 = 32 * NW * WN;
-    constexpr int PLANE2 = P1 * 32, CHUNK2 = 3 * PLANE2;
+    constexpr int NPB = MATH ? 2 : 3;            // planes of a staged / parked activation
+    constexpr int NPA = MATH ? 2 : 3;            // packed planes of a weight
+    constexpr unsigned ABLK = NPA * 1024u;
+    constexpr int PLANE2 = P1 * 32, CHUNK2 = NPB * PLANE2;
     constexpr int MAXSLOT = (P1 + MAX_HALO) / 32;
     constexpr int ITEMS = (NCH * MAXSLOT + NWAVE - 1) / NWAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
@@ -442,8 +526,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     const int l31 = lane & 31, half = lane >> 5;
     const int W1 = P1 + 2 * h1, nslot = (W1 + 31) >> 5;
     const int w0 = n0 - h2 - h1;
-    const int plane1 = wst * 32, chunk1 = 3 * plane1;
+    const int plane1 = wst * 32, chunk1 = NPB * plane1;
     const unsigned ld4 = (unsigned)G.ld * 4u;
+    float amax = 0.f;
 
     // ---- stage the whole window: item t = (chunk, slot of 32 positions), wave w owns items w, w + NWAVE, ...
     {
@@ -472,11 +557,18 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = xr[i][e] < 0.f ? xr[i][e] * G.slope : xr[i][e];
-                u32x4 ph, pm, pl;
-                split8(v, ph, pm, pl);
-                *(u32x4*)(smem3 + lw[i]) = ph;
-                *(u32x4*)(smem3 + plane1 + lw[i]) = pm;
-                *(u32x4*)(smem3 + 2 * plane1 + lw[i]) = pl;
+                if constexpr (MATH == 0) {
+                    u32x4 ph, pm, pl;
+                    split8(v, ph, pm, pl);
+                    *(u32x4*)(smem3 + lw[i]) = ph;
+                    *(u32x4*)(smem3 + plane1 + lw[i]) = pm;
+                    *(u32x4*)(smem3 + 2 * plane1 + lw[i]) = pl;
+                } else {
+                    u32x4 ph, pl;
+                    split8h(v, ph, pl, amax);
+                    *(u32x4*)(smem3 + lw[i]) = ph;
+                    *(u32x4*)(smem3 + plane1 + lw[i]) = pl;
+                }
             }
         }
     }
@@ -488,39 +580,32 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
         for (int q = 0; q < NW; q++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][q][r] = 0.f;
-    const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * 3072u;
-    u32x4 fa[2][MW][3], fb[2][NW][3];
-    auto mfmas = [&](u32x4 (&ac)[MW][3], u32x4 (&bc)[NW][3]) {
-#pragma unroll
-        for (int p = 0; p < 6; p++)
-#pragma unroll
-            for (int i = 0; i < MW; i++)
-#pragma unroll
-                for (int q = 0; q < NW; q++) acc[i][q] = mfma_bf16(ac[i][kProdA[p]], bc[q][kProdB[p]], acc[i][q]);
-    };
+    const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * ABLK;
+    u32x4 fa[2][MW][NPA], fb[2][NW][NPB];
+    auto mfmas = [&](u32x4 (&ac)[MW][NPA], u32x4 (&bc)[NW][NPB]) { step_mfmas<MATH, MW, NW, NPA, NPB>(acc, ac, bc); };
     __syncthreads();
     TT_STAMP(1);
 
     // ================= phase 1: conv1 on the P1 columns [n0 - h2, n0 - h2 + P1) =================
     {
         const int nsteps = NCH * a.k1;
-        const rsrc_t wrs = make_rsrc(a.wb1, (unsigned)(nsteps * NRT * 3072));
-        auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
-            const unsigned sb = (unsigned)s * (unsigned)(NRT * 3072);
+        const rsrc_t wrs = make_rsrc(a.wb1, (unsigned)(nsteps * NRT) * ABLK);
+        auto load_a = [&](int s, u32x4 (&dst)[MW][NPA]) {
+            const unsigned sb = (unsigned)s * ((unsigned)NRT * ABLK);
 #pragma unroll
             for (int i = 0; i < MW; i++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
+                for (int pl = 0; pl < NPA; pl++)
+                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)i * ABLK + (unsigned)(pl * 1024)), 0));
         };
         const int p0 = wn * NW * 32 + l31;
-        auto load_b = [&](int c, int j, u32x4 (&dst)[NW][3]) {
+        auto load_b = [&](int c, int j, u32x4 (&dst)[NW][NPB]) {
             const int p = p0 + j * d;
             const unsigned char* sb = smem3 + c * chunk1 + p * 32 + ((half ^ ((p >> 3) & 1)) << 4);
 #pragma unroll
             for (int q = 0; q < NW; q++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * plane1 + q * 1024);
+                for (int pl = 0; pl < NPB; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * plane1 + q * 1024);
         };
         int sj = 0, sc = 0;
         load_a(0, fa[0]);
@@ -562,17 +647,24 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    float t1 = acc[i][q][hh * 8 + e] + b1v[hh * 8 + e];
+                    float t1 = (MATH ? acc[i][q][hh * 8 + e] * a.ws1 : acc[i][q][hh * 8 + e]) + b1v[hh * 8 + e];
                     t1 = t1 < 0.f ? t1 * G.slope : t1;
                     v[e] = inside ? t1 : 0.f;
                     acc[i][q][hh * 8 + e] = 0.f;
                 }
-                u32x4 ph, pm, pl;
-                split8(v, ph, pm, pl);
                 unsigned char* dst = smem3 + cc * CHUNK2 + col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
-                *(u32x4*)(dst) = ph;
-                *(u32x4*)(dst + PLANE2) = pm;
-                *(u32x4*)(dst + 2 * PLANE2) = pl;
+                if constexpr (MATH == 0) {
+                    u32x4 ph, pm, pl;
+                    split8(v, ph, pm, pl);
+                    *(u32x4*)(dst) = ph;
+                    *(u32x4*)(dst + PLANE2) = pm;
+                    *(u32x4*)(dst + 2 * PLANE2) = pl;
+                } else {
+                    u32x4 ph, pl;
+                    split8h(v, ph, pl, amax);
+                    *(u32x4*)(dst) = ph;
+                    *(u32x4*)(dst + PLANE2) = pl;
+                }
             });
         });
     });
@@ -607,23 +699,23 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     // ================= phase 2: conv2 (dilation 1) out of the parked intermediate =================
     {
         const int nsteps = NCH * a.k2;
-        const rsrc_t wrs = make_rsrc(a.wb2, (unsigned)(nsteps * NRT * 3072));
-        auto load_a = [&](int s, u32x4 (&dst)[MW][3]) {
-            const unsigned sb = (unsigned)s * (unsigned)(NRT * 3072);
+        const rsrc_t wrs = make_rsrc(a.wb2, (unsigned)(nsteps * NRT) * ABLK);
+        auto load_a = [&](int s, u32x4 (&dst)[MW][NPA]) {
+            const unsigned sb = (unsigned)s * ((unsigned)NRT * ABLK);
 #pragma unroll
             for (int i = 0; i < MW; i++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)(i * 3072 + pl * 1024)), 0));
+                for (int pl = 0; pl < NPA; pl++)
+                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)i * ABLK + (unsigned)(pl * 1024)), 0));
         };
         const int p0 = wn * NW * 32 + l31;
-        auto load_b = [&](int c, int j, u32x4 (&dst)[NW][3]) {
+        auto load_b = [&](int c, int j, u32x4 (&dst)[NW][NPB]) {
             const int p = p0 + j;
             const unsigned char* sb = smem3 + c * CHUNK2 + p * 32 + ((half ^ ((p >> 3) & 1)) << 4);
 #pragma unroll
             for (int q = 0; q < NW; q++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE2 + q * 1024);
+                for (int pl = 0; pl < NPB; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE2 + q * 1024);
         };
         int sj = 0, sc = 0;
         load_a(0, fa[0]);
@@ -662,7 +754,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
                     if (any) {
                         f32x4u o;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) o[e] = w[e] + b2v[i][g] + xres[i][q][g][e];
+                        for (int e = 0; e < 4; e++) o[e] = (MATH ? w[e] * a.ws2 : w[e]) + b2v[i][g] + xres[i][q][g][e];
                         float* yp = a.y + (size_t)(mbase + i * 32 + 8 * g + 4 * half + lane4) * G.ld + base + pos;
                         if (full) *(f32x4u*)yp = o;
                         else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) yp[e] = o[e]; }
@@ -671,6 +763,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
             });
         });
     }
+    if constexpr (MATH == 1) { if (amax > kH2Limit && G.ovf) *G.ovf = 1u; }
 #ifdef STS_TILE_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TT_STAMP(5);
@@ -698,6 +791,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     unsigned* done = claim + 1;                     // [op][chain][PS_MAX_COLS flags | 1 count]
     unsigned next = 0;
     if (tid == 0) next = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef STS_TILE_TRACE
+    long long ps_t0 = (long long)__builtin_amdgcn_s_memtime(), ps_wait = 0, ps_items = 0;
+#endif
     {
         const int nw = nops * nmem * (int)(sizeof(ConvArgs) / 4);
         const int* src = (const int*)(A.tab + (size_t)x * nops * nmem);
@@ -711,6 +807,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if (tid == 0) next = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next item: its round trip rides under this tile
         const int op = t / (ncol * nmem), rem = t - op * ncol * nmem;
         const int col = rem / nmem, m = rem - col * nmem;
+#ifdef STS_TILE_TRACE
+        const long long ps_w0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
         if (op > 0 && tid == 0) {
             // usually the whole previous op of this chain is complete (one count to look at); otherwise the three column tiles
             // this one reads, all three flags requested together
@@ -727,6 +826,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
         }
         __syncthreads();
+#ifdef STS_TILE_TRACE
+        ps_wait += (long long)__builtin_amdgcn_s_memtime() - ps_w0; ps_items++;
+#endif
         // the conv's descriptor word by word through readfirstlane: every field in scalar registers (read through a pointer the
         // compiler treats the fields as divergent and wraps each buffer load in a waterfall loop: 22 per K step, measured 1.9x slower)
         ConvArgs al;
@@ -749,6 +851,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             __hip_atomic_fetch_add(f + PS_MAX_COLS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef STS_TILE_TRACE
+    if (g_tile_trace && tid == 0) {
+        const unsigned slot = atomicAdd(&g_tile_trace_n, 1u);
+        if (slot < g_tile_trace_cap) {
+            long long* r = g_tile_trace + (size_t)slot * 10;
+            r[0] = (long long)gridDim.x; r[1] = (long long)blockIdx.x; r[2] = 2 | ((long long)x << 40); r[3] = (long long)__builtin_amdgcn_s_memrealtime();
+            r[4] = ps_t0; r[5] = (long long)__builtin_amdgcn_s_memtime(); r[6] = ps_wait; r[7] = ps_items; r[8] = 0; r[9] = 0;
+        }
+    }
+#endif
     // the last workgroup to leave re-arms the counters for the next launch
     __syncthreads();
     unsigned* exitc = A.ctr + 8 * per_xcd;
@@ -774,24 +886,46 @@ static inline void split_host(float x, uint16_t (&p)[3]) {
     p[0] = (uint16_t)(h >> 16); p[1] = (uint16_t)(m >> 16); p[2] = (uint16_t)(w >> 16);
 }
 
-size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst, bool perm_k) {
+// fp16 terms of a scaled weight (MATH 1, see split8h): P0 = fp16(ws), P1 = fp16(ws - P0), P2 = P0 * 2^-11
+static inline uint16_t f16_bits(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }
+static inline void split_host_h2(float ws, uint16_t (&p)[3]) {
+    const _Float16 h = (_Float16)ws;
+    p[0] = f16_bits(ws);
+    p[1] = f16_bits(ws - (float)h);
+    p[2] = 0;                            // (P2 = P0 * 2^-11 is formed in the kernel)
+}
+
+size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst, bool perm_k, int math, float* wscale) {
     const int nchunk = Cin_pad / CK, nrt = Cout_pad / 32;
-    const size_t bytes = (size_t)nphase * nchunk * ntap * nrt * 3072;
+    const int npl = math == 1 ? 2 : 3;                     // packed planes
+    const size_t bytes = (size_t)nphase * nchunk * ntap * nrt * npl * 1024;
     if (!dst) return bytes;
     uint16_t* d = (uint16_t*)dst;
+    float up = 1.0f;
+    if (math == 1) {
+        // per-conv power of two that brings the largest weight into [2^13, 2^14): the small terms of all but vanishing weights
+        // stay fp16-normal, the tile is scaled back by 1 / up (exact) in the kernel
+        float mx = 0.f;
+        const size_t n = (size_t)nphase * ntap * Cin_pad * Cout_pad;
+        for (size_t i = 0; i < n; i++) { const float v = wp[i] < 0.f ? -wp[i] : wp[i]; if (v > mx) mx = v; }
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); up = ldexpf(1.0f, 14 - e); }    // mx = f * 2^e, f in [0.5, 1)
+        if (wscale) *wscale = 1.0f / up;
+    }
     for (int ph = 0; ph < nphase; ph++)
         for (int c = 0; c < nchunk; c++)
             for (int j = 0; j < ntap; j++)
                 for (int rt = 0; rt < nrt; rt++) {
-                    uint16_t* blk = d + ((((size_t)ph * nchunk + c) * ntap + j) * nrt + rt) * 1536;   // 3 planes x 512 bf16
+                    uint16_t* blk = d + ((((size_t)ph * nchunk + c) * ntap + j) * nrt + rt) * (size_t)(npl * 512);   // planes x 512 values
                     const float* slab = wp + ((size_t)ph * ntap + j) * Cin_pad * Cout_pad;
                     for (int l = 0; l < 64; l++) {
                         const int i = l & 31, h = l >> 5;
                         for (int e = 0; e < 8; e++) {
                             uint16_t p[3];
                             const int ci = perm_k ? 8 * (e >> 2) + 4 * h + (e & 3) : 8 * h + e;
-                            split_host(slab[(size_t)(c * CK + ci) * Cout_pad + rt * 32 + i], p);
-                            for (int pl = 0; pl < 3; pl++) blk[pl * 512 + l * 8 + e] = p[pl];
+                            const float wv = slab[(size_t)(c * CK + ci) * Cout_pad + rt * 32 + i];
+                            if (math == 1) split_host_h2(wv * up, p); else split_host(wv, p);
+                            for (int pl = 0; pl < npl; pl++) blk[pl * 512 + l * 8 + e] = p[pl];
                         }
                     }
                 }
@@ -802,6 +936,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
 constexpr int kNumBf3Tiles = 8;      // 6 / 7 (round 3): a wave owns 32 rows x 128 columns -- no two waves of a workgroup fetch the same weight rows
+static bool h2_tile(int tile) { return tile == 0 || tile == 3 || tile == 4 || tile == 20 || tile == 22 || tile == 23; }   // built for MATH 1
 static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 20 && tile < 25); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
@@ -838,30 +973,47 @@ static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed =
     return 4;
 }
 
-template <int MW, int NW, int WM, int WN, int NSUB, int KG>
+template <int MW, int NW, int WM, int WN, int NSUB, int KG, int MATH = 0>
 static constexpr size_t bf3_lds_bytes() {
-    constexpr size_t stage = (size_t)6 * NSUB * (32 * NW * WN + MAX_HALO) * 32;
+    constexpr size_t stage = (size_t)(MATH ? 4 : 6) * NSUB * (32 * NW * WN + MAX_HALO) * 32;
     constexpr size_t xchg = KG > 1 ? (size_t)KG * WM * WN * MW * (NW / KG) * 16 * 64 * 4 : 0;     // partial tiles of the K groups
     return stage > xchg ? stage : xchg;
 }
 
-template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
+// H2: this tile is also built for the two-term fp16 arithmetic (the tiles the automatic choice uses; conv_bf3 / conv_bf3_group
+// send a MATH 1 conv to no other)
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, bool H2 = false>
 static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st, int pm = 0) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     pm = pm && a.transposed && (MW == 1 || a.Cout_pad % (32 * MW) == 0);    // a wave's rows must lie inside one phase
     const int mt = pm ? (a.Cout_pad * nphase + MT - 1) / MT : (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT, ny = pm ? mt : mt * nphase;
+    if constexpr (H2) {
+        if (a.math == 1) {
+            const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG, 1>();
+            hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB, KG, 1>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * KG * 64), lds, st, a, mt, nx, ny, pm);
+            return;
+        }
+    }
     const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG>();
     hipLaunchKernelGGL((conv_bf3_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, ny, a.B)), dim3(WM * WN * KG * 64), lds, st, a, mt, nx, ny, pm);
 }
-template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1>
+template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, bool H2 = false>
 static void launch_bf3_group(const ConvGroup& G, hipStream_t st) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
     const ConvArgs& a = G.g[0];
     const int mt = (a.Cout_pad + MT - 1) / MT;
     const int nx = (a.max_n + NT - 1) / NT;
-    const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG>();
     static const int il = exp_int("STS_BF3_INTERLEAVE", 0);
+    if constexpr (H2) {
+        if (a.math == 1) {
+            const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG, 1>();
+            hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB, KG, 1>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * KG * 64), lds, st, G,
+                               mt, a.B, nx, mt, il & 1);
+            return;
+        }
+    }
+    const size_t lds = bf3_lds_bytes<MW, NW, WM, WN, NSUB, KG>();
     hipLaunchKernelGGL((conv_bf3_group_kernel<MW, NW, WM, WN, NSUB, KG>), dim3(mapped_grid(nx, mt, a.B * G.n)), dim3(WM * WN * KG * 64), lds, st, G,
                        mt, a.B, nx, mt, il & 1);
 }
@@ -889,20 +1041,20 @@ long conv_bf3_blocks(const ConvArgs& a) {
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     const int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
-    if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
+    if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
     switch (tile) {
-        case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
+        case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         // phase-merged rows (transposed convs): 21: 256 x 128 (8 waves)   22: 128 x 128   23: 64 x 128 as two 32-row waves x 2
         case 24: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 4, 1, 2, 2>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
         case 21: launch_bf3<2, 2, 4, 2, 1>(a, nphase, st, 1); break;
-        case 22: launch_bf3<2, 2, 2, 2, 1>(a, nphase, st, 1); break;
-        case 23: launch_bf3<1, 2, 2, 2, 1>(a, nphase, st, 1); break;
-        case 0: launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
+        case 22: launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st, 1); break;
+        case 23: launch_bf3<1, 2, 2, 2, 1, 1, true>(a, nphase, st, 1); break;
+        case 0: launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         case 1: launch_bf3<2, 2, 1, 4, 1>(a, nphase, st); break;
         case 2: launch_bf3<2, 2, 2, 4, 1>(a, nphase, st); break;
-        case 3: launch_bf3<2, 2, 1, 2, 1>(a, nphase, st); break;
-        case 4: launch_bf3<1, 2, 1, 4, 1>(a, nphase, st); break;
+        case 3: launch_bf3<2, 2, 1, 2, 1, 1, true>(a, nphase, st); break;
+        case 4: launch_bf3<1, 2, 1, 4, 1, 1, true>(a, nphase, st); break;
         case 5: launch_bf3<1, 2, 1, 2, 1>(a, nphase, st); break;
         case 6: launch_bf3<1, 4, 4, 1, 1>(a, nphase, st); break;      // 128 x 128, four waves of 32 x 128
         case 7: launch_bf3<1, 4, 2, 1, 1>(a, nphase, st); break;      //  64 x 128, two waves of 32 x 128
@@ -923,7 +1075,7 @@ bool conv_bf3_group_eligible(const ConvGroup& G) {
     for (int i = 0; i < G.n; i++) {
         const ConvArgs& a = G.g[i];
         if (!conv_bf3_eligible(a) || a.transposed || a.epi == EPI_GATE) return false;
-        if (a.Cout_pad != r.Cout_pad || a.max_n != r.max_n || a.B != r.B) return false;
+        if (a.Cout_pad != r.Cout_pad || a.max_n != r.max_n || a.B != r.B || a.math != r.math) return false;
     }
     return true;
 }
@@ -936,18 +1088,18 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
             ConvArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
         }
     const ConvArgs& a = G.g[0];
-    if (!bf3_tile_ok(tile)) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n);
+    if (!bf3_tile_ok(tile) || (a.math == 1 && (!h2_tile(tile) || tile >= 20))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n);
     if (tile >= 8 && tile < 16) for (int i = 0; i < G.n; i++) if (G.g[i].Cin_pad % 32 != 0) { tile -= 8; break; }
     switch (tile) {
         case 20: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
                    if (ok) launch_bf3_group<2, 2, 2, 2, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
         case 24: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
                    if (ok) launch_bf3_group<2, 2, 4, 1, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
-        case 0: launch_bf3_group<2, 2, 2, 2, 1>(G, st); break;
+        case 0: launch_bf3_group<2, 2, 2, 2, 1, 1, true>(G, st); break;
         case 1: launch_bf3_group<2, 2, 1, 4, 1>(G, st); break;
         case 2: launch_bf3_group<2, 2, 2, 4, 1>(G, st); break;
-        case 3: launch_bf3_group<2, 2, 1, 2, 1>(G, st); break;
-        case 4: launch_bf3_group<1, 2, 1, 4, 1>(G, st); break;
+        case 3: launch_bf3_group<2, 2, 1, 2, 1, 1, true>(G, st); break;
+        case 4: launch_bf3_group<1, 2, 1, 4, 1, 1, true>(G, st); break;
         case 5: launch_bf3_group<1, 2, 1, 2, 1>(G, st); break;
         case 6: launch_bf3_group<1, 4, 4, 1, 1>(G, st); break;
         case 7: launch_bf3_group<1, 4, 2, 1, 1>(G, st); break;
@@ -986,10 +1138,14 @@ static void launch_resblock_bf3(const ResLayerGroup& G, hipStream_t st) {
         if (h > halo) halo = h;
     }
     const int wst = (P1 + halo + 31) / 32 * 32;
-    const size_t stage = (size_t)C * wst * 6, park = (size_t)C * P1 * 6 + 1024;    // + slack: conv2's taps of the discarded last columns
+    const size_t pb = G.math == 1 ? 4 : 6;                                          // bytes per staged value: its fp16 / bf16 terms
+    const size_t stage = (size_t)C * wst * pb, park = (size_t)C * P1 * pb + 1024;   // + slack: conv2's taps of the discarded last columns
     const size_t lds = stage > park ? stage : park;
     static const int il = exp_int("STS_BF3_INTERLEAVE", 0);
-    hipLaunchKernelGGL((resblock_bf3_kernel<MW, WM, NW, WN>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx, wst, (il >> 1) & 1);
+    if (G.math == 1)
+        hipLaunchKernelGGL((resblock_bf3_kernel<MW, WM, NW, WN, 1>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx, wst, (il >> 1) & 1);
+    else
+        hipLaunchKernelGGL((resblock_bf3_kernel<MW, WM, NW, WN>), dim3(mapped_grid(nx, 1, G.B * G.n)), dim3(64 * WM * WN), lds, st, G, nx, wst, (il >> 1) & 1);
 }
 
 // variant: -1 automatic; C = 64: 0 = (32 x 64 per wave, 2 x 2 waves), 1 = (64 x 64 per wave, 1 x 2 waves);

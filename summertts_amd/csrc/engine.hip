@@ -29,6 +29,7 @@ Engine::~Engine() {
     if (arenaF_.base) (void)hipFree(arenaF_.base);
     if (pinned_) (void)hipHostFree(pinned_);
     if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
+    if (ovf_host_) (void)hipHostFree(ovf_host_);
     if (hmap_) (void)hipHostFree(hmap_);
     if (arrive_) (void)hipFree(arrive_);
     if (ps_priv_) (void)hipFree(ps_priv_);
@@ -105,6 +106,7 @@ void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); 
 // default arithmetic of the trunk convs: STS_CONV_MATH = bf16x3 (split operands on the bf16 matrix cores, conv_bf3.hip) | f32
 static int default_conv_math() {
     const char* v = getenv("STS_CONV_MATH");
+    if (v && (!strcmp(v, "f16x2") || !strcmp(v, "3"))) return 3;
     return v && (!strcmp(v, "f32") || !strcmp(v, "fp32") || !strcmp(v, "1")) ? 1 : 0;
 }
 
@@ -113,6 +115,7 @@ ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float
     memset(&a, 0, sizeof(a));
     a.x = x; a.x_ld = lin.ld; a.y = y; a.y_ld = lout.ld;
     a.w = c.w; a.wb3 = c.wb3; a.bias = c.bias; a.ubias = o.ubias; a.ubias_ld = lout.nb;
+    if (conv_math == 3 && c.wh2) { a.wb3 = c.wh2; a.math = 1; a.wscale = c.h2_scale; a.ovf = ovf_; }     // "f16x2": the two-term fp16 copy
     a.res = o.res; a.res_ld = o.res_ld ? o.res_ld : lout.ld;
     a.aux = o.aux; a.aux_ld = o.aux_ld ? o.aux_ld : lout.ld;
     a.pcm = o.pcm;
@@ -150,7 +153,7 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     // at which they stop being launch-latency-bound (a batch of a few dozen utterances); conv_math 2 = wherever eligible (tests)
     if (conv_mode == 0 && conv_math != 1 && o.tile < 0 && conv_bf3_eligible(a) &&
         (in_mfma_region_ || conv_math == 2 || conv_bf3_blocks(a) >= 384)) {
-        if (in_mfma_region_) { mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_++; }
+        if (in_mfma_region_) { mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_++; }
         static const int bt = exp_int("STS_BF3_TILE", -1);   // experiment knob
         conv_bf3(a, cur_, bt);
     } else if (can_mfma) {
@@ -959,7 +962,7 @@ bool Engine::stage_persistent(RunCtx& c, int i, const float* bup, const Lvl& l2,
                 (void)conv_args(rb.c2[d], bup, l2, reg, l2, o2, &f); fl += f;
             }
         }
-        mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_ += 1;
+        mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_ += 1;
     }
     if (hipMemcpyAsync(ps_tab_, ps_tab_host_, ntab * sizeof(ConvArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
     StageArgs A;
@@ -1082,6 +1085,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
                     R.g[j].x = cur[j]; R.g[j].y = nxt; R.g[j].w1 = c1.w; R.g[j].b1 = c1.bias; R.g[j].w2 = c2.w; R.g[j].b2 = c2.bias;
                     R.g[j].k1 = c1.k; R.g[j].dil1 = c1.dil; R.g[j].k2 = c2.k; R.g[j].wu1 = c1.wu; R.g[j].wu2 = c2.wu;
                     R.g[j].wb1 = c1.wb3; R.g[j].wb2 = c2.wb3p;
+                    if (conv_math == 3 && c1.wh2 && c2.wh2p) { R.g[j].wb1 = c1.wh2; R.g[j].wb2 = c2.wh2p; R.g[j].ws1 = c1.h2_scale; R.g[j].ws2 = c2.h2_scale; R.math = 1; R.ovf = ovf_; }
                 }
                 // the 128-channel variant runs 8-wave workgroups, two per CU: only worth it when the grid fills the chip twice
                 if (fuse && R.C > 64) fuse = (long)((l2.max_len + 117) / 118) * l2.nb * nk >= 512;
@@ -1103,7 +1107,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
                     if (bf3_layer && resblock_bf3_eligible(R)) {
                         static const int bv = exp_int("STS_BF3_LAYER_VARIANT", -1);   // experiment knob
                         resblock_bf3(R, stream, bv);
-                        mfma_flops_ += fl; bf16_exec_ += 6.0 * fl; mfma_launches_ += 1;
+                        mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_ += 1;
                         continue;
                     }
                     if (per_chain) {
@@ -1146,7 +1150,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
                     const int bt = bgt && (int)strlen(bgt) > i ? (bgt[i] >= '0' && bgt[i] <= '9' ? bgt[i] - '0' : (bgt[i] >= 'a' && bgt[i] <= 'z' ? bgt[i] - 'a' + 10 : -1)) : -1;
                     conv_bf3_group(G1, stream, bt);
                     conv_bf3_group(G2, stream, bt);
-                    mfma_flops_ += fl1 + fl2; bf16_exec_ += 6.0 * (fl1 + fl2); mfma_launches_ += 2;
+                    mfma_flops_ += fl1 + fl2; bf16_exec_ += products() * (fl1 + fl2); mfma_launches_ += 2;
                     continue;
                 }
                 if (conv_group_eligible(G1)) conv_mfma_group(G1, stream, gtile);
@@ -1231,7 +1235,34 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
     return STS_OK;
 }
 
+// The two-term fp16 arithmetic (conv_math 3) cannot hold an activation beyond fp16's range; its kernels raise a word in
+// host-mapped memory when they stage one, and the whole utterance batch is then repeated in the split-bf16 form -- results never
+// depend on the flag being rare.  Streaming hands PCM out before the run ends, so it stays on split-bf16.
 int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss) {
+    if (conv_math != 3) return run_once(B, ids, n, sid, ls, ss);
+    HIPCK(hipSetDevice(device));
+    if (!ovf_host_) {
+        if (hipHostMalloc((void**)&ovf_host_, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&ovf_, ovf_host_, 0) != hipSuccess) {
+            if (ovf_host_) (void)hipHostFree(ovf_host_);
+            ovf_host_ = nullptr; ovf_ = nullptr;
+            return fail(STS_EDEVICE, "host-mapped allocation failed");
+        }
+    }
+    *(volatile unsigned*)ovf_host_ = 0u;
+    if (ss) conv_math = 0;
+    const bool forced = have_forced;          // (a run consumes the forced durations: the repeat needs them again)
+    int rc = run_once(B, ids, n, sid, ls, ss);
+    if (rc == STS_OK && !ss && *(volatile unsigned*)ovf_host_ != 0u) {
+        h2_fallbacks++;
+        conv_math = 0;
+        have_forced = forced;
+        rc = run_once(B, ids, n, sid, ls, ss);
+    }
+    conv_math = 3;
+    return rc;
+}
+
+int Engine::run_once(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss) {
     Model& M = model;
     if (B <= 0 || !ids || !n) return fail(STS_EINVAL, "empty batch");
     if (ss && (B != 1 || ss->chunk_frames <= 0 || !ss->cb)) return fail(STS_EINVAL, "streaming takes one utterance, a positive chunk size and a callback");
@@ -1305,6 +1336,7 @@ int Engine::run_output(RunCtx& c) {
     prof.flops_text_encoder = flops_[0]; prof.flops_duration = flops_[1]; prof.flops_flow = flops_[2]; prof.flops_decoder = flops_[3];
     prof.flops_decoder_mfma = mfma_flops_; prof.decoder_mfma_launches = mfma_launches_; prof.bytes_decoder_min = bytes_[3] + 2.0 * (double)Ntot;
     prof.flops_decoder_mfma_executed = mfma_exec_; prof.flops_decoder_bf16_issued = bf16_exec_;
+    prof.conv_math_fallbacks = h2_fallbacks;
     prof.bytes_text_encoder = bytes_[0]; prof.bytes_duration = bytes_[1]; prof.bytes_flow = bytes_[2];
     prof.ms_sync_wait_host = (float)sync_wait_ms_;
     if (profiling) {

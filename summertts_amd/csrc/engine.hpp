@@ -52,6 +52,7 @@ public:
     ~Engine();
     int init(const float* blob, int64_t bytes, int device);
     int run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss = nullptr);
+    int run_once(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss);
     const std::string& error() const { return err_; }
 
     Model model;
@@ -69,7 +70,9 @@ public:
     std::vector<int32_t> forced_dur; bool have_forced = false;
     bool record_taps = false, profiling = false;
     int conv_mode = 0;
-    int conv_math = 0;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA (sts_set_conv_math)
+    int conv_math = 0;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA, 3 = two-term fp16 (sts_set_conv_math)
+    long h2_fallbacks = 0;             // runs repeated in split-bf16 because an activation left fp16's range (conv_math 3)
+    double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
     bool pk_trace = false;             // record the persistent kernel's per-op timeline into taps["pk_trace"] (sts_debug_set)
     int trunk_mode = 0;                // 0 automatic (today: grouped launches), 1 grouped launches, 2 persistent stage kernel where eligible (sts_debug_set)
@@ -103,6 +106,7 @@ private:
     Arena arenaT_, arenaF_;
     char* pinned_ = nullptr; size_t pinned_cap_ = 0;
     char* pinned_pcm_ = nullptr; size_t pinned_pcm_cap_ = 0;
+    unsigned* ovf_host_ = nullptr; unsigned* ovf_ = nullptr;              // conv_math 3: overflow word (host-mapped) and its device address
     int* hmap_ = nullptr; int* hmap_dev_ = nullptr; size_t hmap_cap_ = 0;   // host-mapped result block of the durations kernel
     unsigned* arrive_ = nullptr; int seq_ = 0;
     // persistent decoder-stage kernel (conv_bf3_stage): per-XCD private stage buffers, the conv table and its counters

@@ -66,6 +66,10 @@ struct ConvArgs {
     // optional restriction of the OUTPUT to the columns n in [keep_lo, keep_hi) (keep_hi == 0: all): a window of the persistent
     // stage kernel computes its halo columns but must not publish them (plain / residual epilogue of non-polyphase convs only)
     int keep_lo, keep_hi;
+    // arithmetic of the wb3 copy (conv_bf3.hip): 0 = three bf16 terms / six products, 1 = two fp16 terms / three products with the
+    // weights scaled by a power of two (wscale = its inverse, applied to the finished tile); ovf (math 1): raised when a staged
+    // input value does not fit fp16
+    int math; float wscale; unsigned* ovf;
 };
 
 // Segmented Winograd F(2,3): a k-tap filter is cut into n3 three-tap segments followed by n2 two-tap segments
@@ -197,11 +201,13 @@ struct ResLayerArgs {
     int k1, dil1, k2;
     const float *wu1, *wu2;                   // Winograd-domain copies [seg][4][C][C] (wino_pack) or null
     const void *wb1, *wb2;                    // split-bf16 copies (bf3_pack; wb2 with the k order of the parked intermediate) or null
+    float ws1, ws2;                           // ResLayerGroup::math 1: inverse weight scales of wb1 / wb2 (ConvArgs::wscale)
 };
 struct ResLayerGroup {
     ResLayerArgs g[kMaxGroup];                // must stay the first member (indexed through the kernarg pointer)
     int n, C; long ld; float slope;
     SegView seg; int B; int max_n;
+    int math; unsigned* ovf;                  // arithmetic of wb1 / wb2 and its overflow flag (ConvArgs::math / ovf)
 };
 bool resblock_layer_eligible(const ResLayerGroup& G);
 void resblock_layer(const ResLayerGroup& G, hipStream_t st);
@@ -221,7 +227,9 @@ void conv_bf3_group(const ConvGroup& G, hipStream_t st, int tile = -1);
 // -> dst: [slab-major, see conv_bf3.hip] 3 x bf16; returns the number of bytes written (dst == null: size query)
 // perm_k: the 16 input channels of a chunk in the order the fused layer kernel parks its intermediate in (k slot (h, e) of a
 // chunk = channel 8 (e >> 2) + 4 h + (e & 3): the accumulator rows one lane holds)
-size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst, bool perm_k = false);
+// math 1: the two-term fp16 form of the same layout (three planes P0 / P1 / P2, conv_bf3.hip MATH 1); *wscale receives the inverse
+// of the power of two the weights were scaled by
+size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad, void* dst, bool perm_k = false, int math = 0, float* wscale = nullptr);
 // one ResBlock1 layer on the bf16 matrix cores: x + conv2(lrelu(conv1_dilated(lrelu(x)))), whole input window staged once
 bool resblock_bf3_eligible(const ResLayerGroup& G);
 void resblock_bf3(const ResLayerGroup& G, hipStream_t st, int variant = -1);

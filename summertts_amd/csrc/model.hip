@@ -92,7 +92,7 @@ struct Store {
         int device = 0;
         (void)hipGetDevice(&device);
         vmm = vmm_probe(device, &gran);
-        cap = vmm ? blob_floats * 8 + (16u << 20) : blob_floats * 4 + (8u << 20);
+        cap = vmm ? blob_floats * 8 + (16u << 20) : blob_floats * 6 + (8u << 20);
         host.p = (float*)calloc(cap, sizeof(float));
         if (!host.p) return false;
         if (vmm) {
@@ -100,7 +100,7 @@ struct Store {
             void* va = nullptr;
             if (hipMemAddressReserve(&va, reserved, 0, nullptr, 0) == hipSuccess) { dev = (float*)va; return true; }
             (void)hipGetLastError();
-            vmm = false; cap = blob_floats * 4 + (8u << 20);
+            vmm = false; cap = blob_floats * 6 + (8u << 20);
         }
         return hipMalloc((void**)&dev, cap * sizeof(float)) == hipSuccess;
     }
@@ -213,6 +213,13 @@ bool pack_bf3(Store& st, DConv& d, bool perm_k = false) {
     const float* wh = st.host.data() + (d.w - st.dev);
     bf3_pack(wh, nphase, ntap, d.Cin_pad, d.Cout_pad, p, perm_k);
     if (perm_k) d.wb3p = dptr; else d.wb3 = dptr;
+    // the two-term fp16 form of the same copy (conv math "f16x2"; same layout and size)
+    const float* hptr = nullptr;
+    const size_t hbytes = bf3_pack(nullptr, nphase, ntap, d.Cin_pad, d.Cout_pad, nullptr, false, 1);
+    float* q = st.alloc((hbytes + 3) / 4 + 1024, &hptr);
+    if (!q) return false;
+    bf3_pack(wh, nphase, ntap, d.Cin_pad, d.Cout_pad, q, perm_k, 1, &d.h2_scale);
+    if (perm_k) d.wh2p = hptr; else d.wh2 = hptr;
     return true;
 }
 

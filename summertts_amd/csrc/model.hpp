@@ -36,6 +36,9 @@ struct DConv {
     const float* wk8 = nullptr;     // [tap][Cin_pad / 8][Cout_pad][8] copy for the persistent flow kernel (persist.hip)
     const void* wb3 = nullptr;      // split-bf16 copy (conv_bf3.hip: three bf16 planes, fragment order) of the decoder trunk convs
     const void* wb3p = nullptr;     // the same with the k order of resblock_bf3_kernel's parked intermediate (second conv of a narrow ResBlock layer)
+    const void* wh2 = nullptr;      // two-term fp16 copy in wb3's layout (conv_bf3.hip MATH 1), weights scaled by 1 / h2_scale (a power of two)
+    const void* wh2p = nullptr;     // ... in wb3p's k order
+    float h2_scale = 1.0f;
     double macs_per_out = 0;   // true-tap MACs per output position (all output channels)
 };
 struct DLn { int C = 0; const float* g = nullptr; const float* b = nullptr; };

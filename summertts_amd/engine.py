@@ -38,7 +38,8 @@ class Profile(C.Structure):
                 ("flops_decoder_mfma", C.c_double), ("bytes_decoder_min", C.c_double), ("frames", C.c_int64),
                 ("samples", C.c_int64), ("phonemes", C.c_int64), ("flops_decoder_mfma_executed", C.c_double),
                 ("bytes_text_encoder", C.c_double), ("bytes_duration", C.c_double), ("bytes_flow", C.c_double),
-                ("ms_sync_wait_host", C.c_float), ("flops_decoder_bf16_issued", C.c_double)]
+                ("ms_sync_wait_host", C.c_float), ("flops_decoder_bf16_issued", C.c_double),
+                ("conv_math_fallbacks", C.c_int64)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -204,8 +205,9 @@ class Synthesizer:
 
     def set_conv_math(self, mode):
         """Arithmetic of the decoder trunk convs: 0 / 'bf16x3' = fp32 operands as three bf16 terms on the bf16 matrix cores
-        (default), 1 / 'f32' = the exact-fp32 MFMA instruction."""
-        m = {"bf16x3": 0, "f32": 1, "bf16x3_all": 2}.get(mode, mode)
+        (default), 1 / 'f32' = the exact-fp32 MFMA instruction, 3 / 'f16x2' = two fp16 terms, three products (a call whose
+        activations leave fp16's range is repeated as 'bf16x3'; Profile.conv_math_fallbacks counts them)."""
+        m = {"bf16x3": 0, "f32": 1, "bf16x3_all": 2, "f16x2": 3}.get(mode, mode)
         _check(self.lib, self.lib.sts_set_conv_math(self.h, int(m)))
 
     def set_conv_mode(self, mode: int):

@@ -62,7 +62,7 @@ def test_conv_kernels_against_torch_fp32(case):
     assert np.array_equal(y, y1)
 
 
-CONV_MATHS = ["bf16x3", "f32", "bf16x3_all"]   # sts_set_conv_math 0 (default) / 1 / 2: same tolerances for all three
+CONV_MATHS = ["bf16x3", "f32", "bf16x3_all", "f16x2"]   # sts_set_conv_math 0 (default) / 1 / 2 / 3: same tolerances for all four
 
 BF3_CASES = [c for c in CONV_CASES if not c[7] and c[0] >= 32 and c[0] % 16 == 0 and c[1] >= 32] + [
     (512, 256, 16, 4, 1, 70, 8, False), (128, 96, 3, 1, 1, 4000, 0, False), (32, 32, 7, 9, 3, 5000, 0, False)]
@@ -104,6 +104,94 @@ def test_bf3_conv_is_as_accurate_as_the_fp32_matrix_core_kernel(case):
     y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=13)
     y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=13)
     assert np.array_equal(y, y1)
+
+
+H2_MODES = (50, 60, 63, 64, 80, 82, 83)     # two-term fp16 form: automatic tile, tile codes 0 / 3 / 4 / 20 (K groups) / 22 / 23 (phase-merged)
+
+
+@pytest.mark.parametrize("case", BF3_CASES, ids=str)
+def test_f16x2_conv_against_float64(case):
+    """Two-term fp16 conv (conv_bf3.hip MATH 1: x = hi + 2^-11 lo', weights scaled per conv, three products) against a float64
+    convolution: the 2e-5 bound of every other conv kernel, an RMS error within 2x the exact-fp32 MFMA kernel's, and no
+    dependence on the operands' magnitude -- weights scaled by 2^-20 .. 2^9 and inputs by 2^-8 .. 2^10 give the scaled result
+    to the same relative accuracy.  (Activations have an ABSOLUTE error floor instead, 2^-36 per value: a tensor that is
+    entirely below ~1e-5 -- the 2^-20 case -- is only good to ~1e-5 relative.)"""
+    import torch
+    import torch.nn.functional as F
+    ci, co, k, pad, dil, L, st, dw = case
+    rng = np.random.default_rng(ci * 977 + co + k)
+    x = (rng.standard_normal((ci, L)) * rng.uniform(0.05, 3.0, (ci, 1))).astype(np.float32)
+    w = (rng.standard_normal((co, k, ci)) / np.sqrt(k * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+
+    def ref64(x, w, b):
+        xt = torch.from_numpy(x).double()[None]
+        if st:
+            return F.conv_transpose1d(xt, torch.from_numpy(w).double().permute(2, 0, 1).contiguous(), torch.from_numpy(b).double(), stride=st, padding=pad)[0].numpy()
+        return F.conv1d(xt, torch.from_numpy(w).double().permute(0, 2, 1).contiguous(), torch.from_numpy(b).double(), padding=pad, dilation=dil)[0].numpy()
+
+    ref = ref64(x, w, b)
+    y32 = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=2 + 4)
+    e32 = np.sqrt(np.mean((y32 - ref) ** 2))
+    outs = []
+    for mode in H2_MODES:
+        y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, mode=mode)
+        assert y.shape == ref.shape
+        err = np.abs(y - ref)
+        assert err.max() <= 2e-5, (case, mode, err.max())
+        assert np.sqrt(np.mean(err ** 2)) <= 2.0 * e32 + 1e-9, (case, mode, np.sqrt(np.mean(err ** 2)), e32)
+        outs.append(y)
+    # operand magnitudes: the result scales, its relative error does not
+    zero = np.zeros_like(b)
+    base = ref64(x, w, zero)
+    rms = np.sqrt(np.mean(base ** 2))
+    for sx, sw, tol in ((2.0 ** -8, 1.0, 1e-6), (1.0, 2.0 ** -20, 1e-6), (2.0 ** 10, 1.0, 1e-6), (2.0 ** -6, 2.0 ** 9, 1e-6), (2.0 ** 10, 2.0 ** -18, 1e-6),
+                        (2.0 ** -20, 1.0, 3e-5)):
+        y = engine.debug_conv1d((x * np.float32(sx)).astype(np.float32), (w * np.float32(sw)).astype(np.float32), zero, pad, dil, st, dw, mode=50)
+        rel = np.sqrt(np.mean((y / (sx * sw) - base) ** 2)) / rms
+        assert rel <= tol, (case, sx, sw, rel)
+    # fused input leaky-relu is applied before the split
+    y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=50)
+    y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=50)
+    assert np.array_equal(y, y1)
+
+
+def test_f16x2_falls_back_when_an_activation_leaves_the_fp16_range():
+    """A model whose decoder activations exceed 65504 (conv_pre weights scaled up) trips the overflow word of the two-term fp16
+    kernels; the engine repeats the call in the split-bf16 form, counts it, and returns exactly the split-bf16 result."""
+    cfg = sb.full_cfg("hifigan_sdp")
+    blob = sb.make_blob(cfg, 5)
+    ids = sb.synthetic_ids(20, cfg.vocab)
+    syn = engine.Synthesizer(blob)
+    syn.set_profiling(True)
+    syn.set_forced_durations([3] * len(ids))
+    syn.set_conv_math("f16x2")
+    syn.run_batch([ids])
+    assert syn.profile()["conv_math_fallbacks"] == 0
+    syn.close()
+    # the decoder's input conv is the first conv after the text encoder and the generator header in the blob (synth_blob.make_blob)
+    w = sb._W(5)
+    w.ints(cfg.is_ms, cfg.lang, cfg.dur_type, cfg.dec_type)
+    sb._text_encoder(w, cfg)
+    sb._gen_hdr(w, cfg)
+    start = w.n + 6
+    assert tuple(blob[w.n:w.n + 3].astype(int)) == (cfg.up_init, cfg.inter, 7)
+    big = blob.copy()
+    big[start:start + cfg.up_init * 7 * cfg.inter] *= np.float32(3.0e6)
+    syn = engine.Synthesizer(big)
+    syn.set_profiling(True)
+    syn.set_forced_durations([3] * len(ids))
+    syn.set_conv_math("bf16x3")
+    syn.run_batch([ids])
+    want = syn.pcm_host().copy()
+    syn.set_conv_math("f16x2")
+    syn.set_forced_durations([3] * len(ids))          # (one run consumes them -- and the repeat inside the call needs them again)
+    syn.run_batch([ids])
+    assert syn.profile()["conv_math_fallbacks"] == 1
+    assert np.array_equal(syn.pcm_host(), want)
+    syn.run_batch([ids])
+    assert syn.profile()["conv_math_fallbacks"] == 2
+    syn.close()
 
 
 def test_bf3_conv_random_shapes_against_float64():
@@ -160,7 +248,7 @@ def test_conv_math_setting_is_validated_and_reported():
     ids = sb.synthetic_ids(24, cfg.vocab)
     syn = engine.Synthesizer(blob)
     with pytest.raises(engine.StsError):
-        syn.set_conv_math(3)
+        syn.set_conv_math(4)
     with pytest.raises(engine.StsError):
         syn.set_conv_math(-1)
     syn.set_profiling(True)
@@ -173,8 +261,11 @@ def test_conv_math_setting_is_validated_and_reported():
         if math == "f32":
             assert pr["flops_decoder_bf16_issued"] == 0.0
         else:
-            assert pr["flops_decoder_mfma"] > 0 and abs(pr["flops_decoder_bf16_issued"] / pr["flops_decoder_mfma"] - 6.0) < 1e-6
+            products = 3.0 if math == "f16x2" else 6.0
+            assert pr["flops_decoder_mfma"] > 0 and abs(pr["flops_decoder_bf16_issued"] / pr["flops_decoder_mfma"] - products) < 1e-6
+            assert pr["conv_math_fallbacks"] == 0
     assert np.abs(pcm["bf16x3"] - pcm["f32"]).max() <= 1 and np.abs(pcm["bf16x3_all"] - pcm["f32"]).max() <= 1
+    assert np.abs(pcm["f16x2"] - pcm["f32"]).max() <= 1
     syn.close()
 
 

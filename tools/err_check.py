@@ -11,7 +11,7 @@ cfg = sb.full_cfg("hifigan_sdp"); blob = sb.make_blob(cfg, 1234)
 ids = sb.synthetic_ids(72, cfg.vocab, salt=3)
 o = pyref.RefModel(blob).infer_ids(ids, 0, 1.0)
 syn = engine.Synthesizer(blob); syn.set_record_taps(True)
-for math in ("bf16x3", "f32", "bf16x3_all"):
+for math in ("bf16x3", "f32", "bf16x3_all", "f16x2"):
     syn.set_conv_math(math); syn.run_batch([ids])
     w = syn.tap("wave")[0]; d = w - o["wave"]
     p = syn.pcm_host().astype(np.int32) - o["pcm"].astype(np.int32)

@@ -71,6 +71,18 @@ for li, idx in enumerate(launches):
         ph = f"stage {f(st)}  conv1 {f(c1)}  park {f(pk)}  conv2 {f(c2)}  epilogue {f(ep)}"
         share = 100 * (st.sum() + pk.sum() + ep.sum()) / (st.sum() + c1.sum() + pk.sum() + c2.sum() + ep.sum())
     print(f"{li:7d} {'fused' if kind else 'conv '} {len(q):5d} {end.max():8.1f} | {ph:110s} | {share:9.1f} % | {first}")
+# persistent stage kernel: per workgroup lifetime, time spent waiting for dependencies, items (records of kind 2)
+k2 = r[(r[:, 2] & 0xff) == 2]
+if len(k2):
+    life = (k2[:, 5] - k2[:, 4]) * TICK / 1e3; wait = k2[:, 6] * TICK / 1e3
+    xc = (k2[:, 2] >> 40) & 0xf
+    print(f"stage kernel: {len(k2)} workgroups, lifetime mean {life.mean():.1f} us (max {life.max():.1f}), dependency wait mean {wait.mean():.1f} us "
+          f"({100 * wait.sum() / life.sum():.1f} % of lifetime), items per workgroup mean {k2[:, 7].mean():.1f} (min {k2[:, 7].min()}, max {k2[:, 7].max()})")
+    for x in range(8):
+        sel = xc == x
+        if sel.any():
+            print(f"  XCD {x}: {int(sel.sum())} workgroups, lifetime {life[sel].mean():7.1f} us, wait {wait[sel].mean():6.1f} us, items {k2[sel, 7].sum()}")
+r = r[(r[:, 2] & 0xff) != 2]
 # placement: which workgroups share a CU?  (HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC id on top)
 if os.environ.get("TT_PLACEMENT"):
     li = int(os.environ["TT_PLACEMENT"])

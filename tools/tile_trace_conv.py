@@ -20,7 +20,8 @@ cap = 1 << 15
 buf = torch.zeros(cap * 10, dtype=torch.int64, device="cuda")
 rng = np.random.default_rng(0)
 for k, dil in ((3, 1), (11, 5)):
-    for mode, mname in ((20, "128x128 (4 waves of 64x64)"), (26, "128x128 (4 waves of 32x128)")):
+    for mode, mname in (((60, "f16x2 128x128 (4 waves of 64x64)"), (20, "bf16x3 128x128 (4 waves of 64x64)")) if os.environ.get("TT_H2") else
+                        ((20, "128x128 (4 waves of 64x64)"), (26, "128x128 (4 waves of 32x128)"))):
         for nwg in (1, 64, 256, 512, 1024, 4096):
             L = 128 * nwg
             x = rng.standard_normal((128, L)).astype(np.float32)
@@ -39,5 +40,5 @@ for k, dil in ((3, 1), (11, 5)):
             kl = (r[:, 6] - r[:, 5]) * TICK / 1e3
             pro = (r[:, 5] - r[:, 4]) * TICK / 1e3
             ep = (r[:, 7] - r[:, 6]) * TICK / 1e3
-            print(f"k={k:2d} {mname:30s} {nwg:5d} workgroups: K loop {kl.mean():7.2f} us = {1e3 * kl.mean() / steps / TICK:6.0f} ticks per step "
-                  f"(24 MFMAs = 768 pipe cycles)   prologue {pro.mean():5.2f}  epilogue {ep.mean():5.2f} us", flush=True)
+            print(f"k={k:2d} {mname:36s} {nwg:5d} workgroups: K loop {kl.mean():7.2f} us = {1e3 * kl.mean() / steps / TICK:6.0f} ticks per step "
+                  f"({12 if mode >= 60 else 24} MFMAs = {384 if mode >= 60 else 768} pipe cycles)   prologue {pro.mean():5.2f}  epilogue {ep.mean():5.2f} us", flush=True)
