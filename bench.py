@@ -239,9 +239,9 @@ def kernel_build_id() -> str:
 
 
 def _env_conv_math() -> str:
-    """STS_CONV_MATH as the engine reads it (f32 / fp32 / 1 = exact-fp32 MFMA, anything else = split-bf16)."""
+    """STS_CONV_MATH as the engine reads it (f32 / fp32 / 1 = exact-fp32 MFMA, bf16x3 / 0 = split-bf16, anything else = two-term fp16)."""
     v = os.environ.get("STS_CONV_MATH", "")
-    return "f32" if v in ("f32", "fp32", "1") else ("f16x2" if v in ("f16x2", "3") else "bf16x3")
+    return "f32" if v in ("f32", "fp32", "1") else ("bf16x3" if v in ("bf16x3", "0") else "f16x2")
 
 
 def main():
@@ -435,11 +435,11 @@ def main():
 
     gpu_out = {args.conv_math: capture_output()}
 
-    # ---- second timed leg (rank 0, one GPU): the same step with the trunk convs on the exact-fp32 MFMA instruction, so that
-    # the line carries both arithmetic paths measured in the same process
-    f32_leg = None
-    if dist is None and not stub and args.conv_math in ("bf16x3", "f16x2") and not args.no_f32_leg and hasattr(syn, "set_conv_math"):
-        syn.set_conv_math("f32")
+    # ---- extra timed legs (rank 0, one GPU): the same step with the trunk convs in the other arithmetics -- the exact-fp32 MFMA
+    # instruction and, under the two-term fp16 default, the split-bf16 form -- so that the line carries every arithmetic path
+    # measured in the same process, each with its parity against the reference
+    def extra_leg(math):
+        syn.set_conv_math(math)
         for _ in range(2):
             step()
         n2 = max(5, args.steps // 2)
@@ -455,15 +455,27 @@ def main():
         e2 = time.perf_counter() - t2
         m2 = acc2.get("ms_decoder_mfma", 0.0)
         a2 = (acc2.get("flops_decoder_mfma", 0.0) / (m2 * 1e-3)) / 1e12 if m2 > 0 else 0.0
-        i2 = (acc2.get("flops_decoder_mfma_executed", 0.0) / (m2 * 1e-3)) / 1e12 if m2 > 0 else 0.0
-        f32_leg = {"value": samples2 / e2, "unit": "samples/s", "x_realtime_16khz": samples2 / e2 / 16000.0, "steps": n2,
-                   "ms_per_step": 1e3 * e2 / n2, "dtype": "f32 (v_mfma_f32_32x32x2_f32, Winograd-domain fused layers)",
-                   "stage_ms_per_step": {k[3:]: acc2.get(k, 0.0) / n2 for k in ("ms_text_encoder", "ms_duration", "ms_flow", "ms_decoder")},
-                   "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": a2 / PEAK_F32_MFMA_TFLOPS, "mfma_issued_tflops": i2,
-                                "mfma_issued_frac": i2 / PEAK_F32_MFMA_TFLOPS}}
-        gpu_out["f32"] = capture_output()
+        leg = {"value": samples2 / e2, "unit": "samples/s", "x_realtime_16khz": samples2 / e2 / 16000.0, "steps": n2,
+               "ms_per_step": 1e3 * e2 / n2,
+               "stage_ms_per_step": {k[3:]: acc2.get(k, 0.0) / n2 for k in ("ms_text_encoder", "ms_duration", "ms_flow", "ms_decoder")}}
+        if math == "f32":
+            i2 = (acc2.get("flops_decoder_mfma_executed", 0.0) / (m2 * 1e-3)) / 1e12 if m2 > 0 else 0.0
+            leg["dtype"] = "f32 (v_mfma_f32_32x32x2_f32, Winograd-domain fused layers)"
+            leg["roofline"] = {"bound": "mfma", "achieved": a2, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": a2 / PEAK_F32_MFMA_TFLOPS, "mfma_issued_tflops": i2, "mfma_issued_frac": i2 / PEAK_F32_MFMA_TFLOPS}
+        else:
+            pk = PEAK_BF16_MFMA_TFLOPS / BF16_PRODUCTS_PER_F32
+            leg["dtype"] = "f32 (3 bf16 terms per operand, 6 bf16 MFMA products per fp32 product)"
+            leg["roofline"] = {"bound": "mfma", "achieved": a2, "peak": pk, "unit": "TFLOP/s", "frac": a2 / pk}
+        gpu_out[math] = capture_output()
         syn.set_conv_math(args.conv_math)
+        return leg
+
+    f32_leg = bf3_leg = None
+    if dist is None and not stub and args.conv_math in ("bf16x3", "f16x2") and not args.no_f32_leg and hasattr(syn, "set_conv_math"):
+        f32_leg = extra_leg("f32")
+        if args.conv_math == "f16x2":
+            bf3_leg = extra_leg("bf16x3")
     ceiling = measured_mfma_ceiling(3 if args.conv_math == "f16x2" else BF16_PRODUCTS_PER_F32) if (dist is None and not stub and rank == 0) else None
 
     # ---- extra figure (not the headline): the native request pool (sts_pool: N engines, one worker thread each,
@@ -625,6 +637,8 @@ def main():
                                         "left un-overlapped when the clock stopped"}
         if f32_leg is not None:
             out["f32_mfma_leg"] = f32_leg
+        if bf3_leg is not None:
+            out["bf16x3_leg"] = bf3_leg
         if pipelined is not None:
             out["request_pool"] = pipelined
         if world == 1 and not args.no_cpu_baseline and not stub:

@@ -109,15 +109,15 @@ int sts_get_durations(sts_engine* e, int32_t* dur, int64_t capacity);
 int sts_set_conv_mode(sts_engine* e, int mode);
 /*   arithmetic of the decoder trunk's matrix-core convs (upsamplers + ResBlock convs, ~95 % of the FLOPs):
  *   0 = fp32 operands split exactly into three bf16 terms each, six bf16 MFMA products per fp32 product, fp32 accumulation
- *       (conv_bf3.hip; as accurate as 1 against float64, 6/16 of its matrix-pipe time) -- the default;
+ *       (conv_bf3.hip; as accurate as 1 against float64, 6/16 of its matrix-pipe time);
  *   1 = the exact-fp32 MFMA instruction (v_mfma_f32_32x32x2_f32) everywhere;
  *   2 = as 0, and also for every other eligible matrix-core conv (flow, text encoder) regardless of its grid size -- by default
  *       those switch to the split form only from the batch size on at which they stop being launch-latency-bound (tests).
  *   3 = "f16x2": fp32 operands as TWO fp16 terms (the small one pre-scaled by 2^11, weights by a per-conv power of two), three
  *       fp16 MFMA products per fp32 product -- half the matrix-pipe time of 0, 22-23 instead of 24 operand bits (measured error
- *       against float64: DESIGN.md 5f).  An activation beyond fp16's range raises a flag and the call is repeated in form 0
- *       (sts_profile.conv_math_fallbacks counts these); streaming calls always use form 0.
- *   The default can also be chosen with the environment variable STS_CONV_MATH = bf16x3 | f32 | f16x2. */
+ *       against float64: DESIGN.md 5f) -- the default.  An activation beyond fp16's range raises a flag and the call (a
+ *       streaming call: the chunk, before it is handed out) is repeated in form 0; sts_profile.conv_math_fallbacks counts these.
+ *   The default can also be chosen with the environment variable STS_CONV_MATH = f16x2 | bf16x3 | f32. */
 int sts_set_conv_math(sts_engine* e, int mode);
 
 /*   test hooks (per engine, never read from the environment): force a kernel family that the automatic choice would not pick

@@ -936,7 +936,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
 constexpr int kNumBf3Tiles = 8;      // 6 / 7 (round 3): a wave owns 32 rows x 128 columns -- no two waves of a workgroup fetch the same weight rows
-static bool h2_tile(int tile) { return tile == 0 || tile == 3 || tile == 4 || tile == 20 || tile == 22 || tile == 23; }   // built for MATH 1
+static bool h2_tile(int tile) { return tile == 0 || tile == 3 || tile == 4 || tile == 20 || tile == 22 || tile == 23 || tile == 6 || tile == 8 || tile == 14; }   // built for MATH 1
 static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 20 && tile < 25); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
@@ -1056,11 +1056,11 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
         case 3: launch_bf3<2, 2, 1, 2, 1, 1, true>(a, nphase, st); break;
         case 4: launch_bf3<1, 2, 1, 4, 1, 1, true>(a, nphase, st); break;
         case 5: launch_bf3<1, 2, 1, 2, 1>(a, nphase, st); break;
-        case 6: launch_bf3<1, 4, 4, 1, 1>(a, nphase, st); break;      // 128 x 128, four waves of 32 x 128
+        case 6: launch_bf3<1, 4, 4, 1, 1, 1, true>(a, nphase, st); break;      // 128 x 128, four waves of 32 x 128
         case 7: launch_bf3<1, 4, 2, 1, 1>(a, nphase, st); break;      //  64 x 128, two waves of 32 x 128
-        case 14: launch_bf3<1, 4, 4, 1, 2>(a, nphase, st); break;
+        case 14: launch_bf3<1, 4, 4, 1, 2, 1, true>(a, nphase, st); break;
         case 15: launch_bf3<1, 4, 2, 1, 2>(a, nphase, st); break;
-        case 8: launch_bf3<2, 2, 2, 2, 2>(a, nphase, st); break;
+        case 8: launch_bf3<2, 2, 2, 2, 2, 1, true>(a, nphase, st); break;
         case 9: launch_bf3<2, 2, 1, 4, 2>(a, nphase, st); break;
         case 10: launch_bf3<2, 2, 2, 4, 2>(a, nphase, st); break;
         case 11: launch_bf3<2, 2, 1, 2, 2>(a, nphase, st); break;

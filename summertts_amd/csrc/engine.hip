@@ -103,11 +103,12 @@ void Engine::stage_begin(int s) { cur_stage_ = s; }
 void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); }
 
 // builds the kernel arguments of one conv and books its FLOPs / minimum HBM bytes
-// default arithmetic of the trunk convs: STS_CONV_MATH = bf16x3 (split operands on the bf16 matrix cores, conv_bf3.hip) | f32
+// default arithmetic of the trunk convs: STS_CONV_MATH = f16x2 (two fp16 terms, three products: the default) | bf16x3 (three bf16
+// terms, six products) | f32 (the exact-fp32 MFMA instruction)          (conv_bf3.hip)
 static int default_conv_math() {
     const char* v = getenv("STS_CONV_MATH");
-    if (v && (!strcmp(v, "f16x2") || !strcmp(v, "3"))) return 3;
-    return v && (!strcmp(v, "f32") || !strcmp(v, "fp32") || !strcmp(v, "1")) ? 1 : 0;
+    if (v && (!strcmp(v, "bf16x3") || !strcmp(v, "0"))) return 0;
+    return v && (!strcmp(v, "f32") || !strcmp(v, "fp32") || !strcmp(v, "1")) ? 1 : 3;
 }
 
 ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o, double* flops) {
@@ -1237,7 +1238,9 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
 
 // The two-term fp16 arithmetic (conv_math 3) cannot hold an activation beyond fp16's range; its kernels raise a word in
 // host-mapped memory when they stage one, and the whole utterance batch is then repeated in the split-bf16 form -- results never
-// depend on the flag being rare.  Streaming hands PCM out before the run ends, so it stays on split-bf16.
+// depend on the flag being rare.  A streaming call checks the word before each chunk leaves: raised during the first chunk (or
+// before it: text encoder, flow) the call starts over, later only that chunk is decoded again -- split-bf16 from there on.
+static constexpr int kRetrySplitBf16 = 1;     // run_once: nothing was handed out, repeat in the split-bf16 form
 int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss) {
     if (conv_math != 3) return run_once(B, ids, n, sid, ls, ss);
     HIPCK(hipSetDevice(device));
@@ -1249,10 +1252,9 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         }
     }
     *(volatile unsigned*)ovf_host_ = 0u;
-    if (ss) conv_math = 0;
     const bool forced = have_forced;          // (a run consumes the forced durations: the repeat needs them again)
     int rc = run_once(B, ids, n, sid, ls, ss);
-    if (rc == STS_OK && !ss && *(volatile unsigned*)ovf_host_ != 0u) {
+    if ((rc == STS_OK && !ss && *(volatile unsigned*)ovf_host_ != 0u) || rc == kRetrySplitBf16) {
         h2_fallbacks++;
         conv_math = 0;
         have_forced = forced;
@@ -1325,6 +1327,13 @@ int Engine::run_output(RunCtx& c) {
             const long ns = (f1 - f0) * hop;
             HIPCK(hipMemcpyAsync(hp, bf.pcm + (f0 - w0) * hop, (size_t)ns * 2, hipMemcpyDeviceToHost, stream));
             HIPCK(hipStreamSynchronize(stream));
+            if (conv_math == 3 && ovf_host_ && *(volatile unsigned*)ovf_host_ != 0u) {
+                if (f0 == 0) return kRetrySplitBf16;          // nothing has left yet (run() repeats the call)
+                h2_fallbacks++;
+                conv_math = 0;                                 // (run() restores the setting)
+                f0 -= ss->chunk_frames;                        // this chunk again
+                continue;
+            }
             total_samples += ns;
             if (ss->cb(ss->user, hp, (int32_t)ns, (int32_t)(f0 * hop)) != 0) break;
         }

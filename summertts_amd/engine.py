@@ -204,8 +204,8 @@ class Synthesizer:
         _check(self.lib, self.lib.sts_set_record_taps(self.h, 1 if on else 0))
 
     def set_conv_math(self, mode):
-        """Arithmetic of the decoder trunk convs: 0 / 'bf16x3' = fp32 operands as three bf16 terms on the bf16 matrix cores
-        (default), 1 / 'f32' = the exact-fp32 MFMA instruction, 3 / 'f16x2' = two fp16 terms, three products (a call whose
+        """Arithmetic of the decoder trunk convs: 0 / 'bf16x3' = fp32 operands as three bf16 terms on the bf16 matrix cores,
+        1 / 'f32' = the exact-fp32 MFMA instruction, 3 / 'f16x2' = two fp16 terms, three products (default; a call whose
         activations leave fp16's range is repeated as 'bf16x3'; Profile.conv_math_fallbacks counts them)."""
         m = {"bf16x3": 0, "f32": 1, "bf16x3_all": 2, "f16x2": 3}.get(mode, mode)
         _check(self.lib, self.lib.sts_set_conv_math(self.h, int(m)))

@@ -191,6 +191,15 @@ def test_f16x2_falls_back_when_an_activation_leaves_the_fp16_range():
     assert np.array_equal(syn.pcm_host(), want)
     syn.run_batch([ids])
     assert syn.profile()["conv_math_fallbacks"] == 2
+    # streaming: the word is checked before the first chunk leaves -- the call starts over in the split-bf16 form
+    syn.set_conv_math("bf16x3")
+    syn.set_forced_durations([3] * len(ids))
+    ref_chunks, _ = syn.infer_ids_stream(ids, 16)
+    syn.set_conv_math("f16x2")
+    syn.set_forced_durations([3] * len(ids))
+    chunks, _ = syn.infer_ids_stream(ids, 16)
+    assert syn.profile()["conv_math_fallbacks"] == 3
+    assert np.array_equal(np.concatenate(chunks), np.concatenate(ref_chunks))
     syn.close()
 
 
@@ -907,14 +916,17 @@ def test_persistent_decoder_stage_kernel_matches_the_grouped_launches():
     blob = sb.make_blob(cfg, 1234)
     syn = engine.Synthesizer(blob)
     syn.set_record_taps(True)
+    syn.set_conv_math("bf16x3")        # (the stage kernel exists for the split-bf16 form only)
+    syn.set_profiling(True)
     for T in (128, 37, 300):
         ids = sb.synthetic_ids(T, cfg.vocab, salt=T)
         out = {}
         for mode in (1, 2, 2):
             syn.debug_set("trunk_mode", mode)
             syn.run_batch([ids])
-            out.setdefault(mode, []).append((syn.pcm_host().copy(), syn.tap("wave")[0].copy()))
-        for pcm, wave in out[2]:
+            out.setdefault(mode, []).append((syn.pcm_host().copy(), syn.tap("wave")[0].copy(), syn.profile()["decoder_mfma_launches"]))
+        assert out[2][0][2] < out[1][0][2], "the persistent stage kernel did not engage"
+        for pcm, wave, _ in out[2]:
             assert np.abs(wave - out[1][0][1]).max() <= 1e-6, (T, np.abs(wave - out[1][0][1]).max())
             assert_pcm_close(pcm, out[1][0][0], f"T={T}: persistent stage vs grouped launches")
         assert np.array_equal(out[2][0][0], out[2][1][0]), "persistent stage kernel is not deterministic"

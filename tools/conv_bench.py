@@ -24,7 +24,7 @@ if os.environ.get("CONV_BENCH_MODES"):
     _only_modes = [int(v) for v in os.environ["CONV_BENCH_MODES"].split(",")]
 else:
     _only_modes = None
-MODES = {13: "bf3", 20: "bf3_128x128", 21: "bf3_64x256", 22: "bf3_128x256w8", 23: "bf3_64x128", 24: "bf3_32x256", 25: "bf3_32x128", 28: "bf3s2_128x128", 29: "bf3s2_64x256", 30: "bf3s2_128x256w8", 31: "bf3s2_64x128", 32: "bf3s2_32x256", 33: "bf3s2_32x128", 26: "bf3_4w32x128", 27: "bf3_2w32x128", 34: "bf3s2_4w32x128", 35: "bf3s2_2w32x128", 40: "kg2_128x128", 41: "pm_256x128", 42: "pm_128x128", 43: "pm_64x128", 44: "kg2_256x64", 12: "wino", 0: "auto", 2: "128x128", 3: "64x256", 4: "32x512", 5: "64x128", 6: "32x128", 7: "32x256", 8: "splitk32", 9: "splitk64"}
+MODES = {50: "h2", 60: "h2_128x128", 66: "h2_4w32x128", 68: "h2s2_128x128", 74: "h2s2_4w32x128", 63: "h2_64x128", 64: "h2_32x256", 13: "bf3", 20: "bf3_128x128", 21: "bf3_64x256", 22: "bf3_128x256w8", 23: "bf3_64x128", 24: "bf3_32x256", 25: "bf3_32x128", 28: "bf3s2_128x128", 29: "bf3s2_64x256", 30: "bf3s2_128x256w8", 31: "bf3s2_64x128", 32: "bf3s2_32x256", 33: "bf3s2_32x128", 26: "bf3_4w32x128", 27: "bf3_2w32x128", 34: "bf3s2_4w32x128", 35: "bf3s2_2w32x128", 40: "kg2_128x128", 41: "pm_256x128", 42: "pm_128x128", 43: "pm_64x128", 44: "kg2_256x64", 12: "wino", 0: "auto", 2: "128x128", 3: "64x256", 4: "32x512", 5: "64x128", 6: "32x128", 7: "32x256", 8: "splitk32", 9: "splitk64"}
 
 def main():
     only = sys.argv[1:] if len(sys.argv) > 1 else None

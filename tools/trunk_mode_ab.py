@@ -16,6 +16,7 @@ syn.set_profiling(True)
 pcm = {}
 for rnd in range(2):
     for mode in (1, 2):
+        syn.set_conv_math("bf16x3")
         syn.debug_set("trunk_mode", mode)
         for _ in range(3):
             syn.run_batch([ids])
