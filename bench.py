@@ -515,7 +515,8 @@ def main():
     # attached only when it was taken with THIS library build on THIS workload.
     traffic = None
     pmc_extra = {}
-    wl_key = f"{args.workload}|batch={args.batch}|phonemes={args.phonemes}|ragged={int(args.ragged)}"
+    wl_key = (f"{args.workload}|batch={args.batch}|phonemes={args.phonemes}|ragged={int(args.ragged)}"
+              + ("" if args.conv_math == "f16x2" else f"|math={args.conv_math}"))      # (the summaries are taken under the default arithmetic)
     build_id = kernel_build_id()
     try:
         pmc_all = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))

@@ -55,12 +55,23 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef STS_VAR
 #define STS_VAR 6
 #endif
+// Lab switches of the two-term fp16 kernels (tools/var_build.sh with VAR_EXTRA / VAR_TAG; every setting computes identical results).
+// Measured on MI355X, one utterance / batch 32 (round 3):
+//   STS_H2_AR     ring of weight fragments of the plain tiles: step s + AR - 1 is requested during step s.  3 and 4: no effect
+//                 (the K loop is not waiting for weights)
+//   STS_H2_WAVES / STS_H2_MINW   most / fewest waves per SIMD the register budget is sized for.  3 / 3 (168 registers, three
+//                 128 x 128 workgroups per CU): +1 % / -2 %
+// tools/h2_decomp.sh (steps with the MFMAs / LDS reads / weight loads compiled out, profiles/r03_f16x2_kloop_decomposition.log): two
+// workgroups per CU spend ~1 070 cycles per 12-MFMA step = the pipe 72 % busy in the K loop (split-bf16: 1 650 per 24 = 93 %);
+// without the weight loads 917, without the LDS reads 1 030.
 #ifndef STS_H2_AR
-#define STS_H2_AR 2         // ring of weight fragments of the two-term fp16 kernels' plain tiles: step s + STS_H2_AR - 1 is requested during step s
+#define STS_H2_AR 2
+#endif
+#ifndef STS_H2_MINW
+#define STS_H2_MINW 1
 #endif
 #ifndef STS_H2_WAVES
-#define STS_H2_WAVES 2      // most waves per SIMD the two-term fp16 kernels are compiled for (lab: VAR_TAG=w3 VAR_EXTRA=-DSTS_H2_WAVES=3 tools/var_build.sh 6:
-                            // 168 registers, three waves per SIMD -- no effect at one utterance, -0.8 % at 32)
+#define STS_H2_WAVES 2
 #endif
 
 #ifdef STS_TILE_TRACE
@@ -452,7 +463,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 }
 
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, int MATH = 0>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(MATH ? STS_H2_MINW : 1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
     const TileId t = map_tile(nx, ny, a.B);
     if (!t.valid) return;
     conv_bf3_body<MW, NW, WM, WN, NSUB, KG, false, MATH>(a, mtiles, t.bx, t.by, t.bz, pm);
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_e
 
 // grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, int MATH = 0>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny, int interleave) {
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(MATH ? STS_H2_MINW : 1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny, int interleave) {
     const TileId t = map_tile(nx, ny, B * G.n);
     if (!t.valid) return;
     // interleave: consecutive dispatch units belong to different members (different K lengths), so that workgroups that
@@ -936,7 +947,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 //   0: 128 x 128 (4 waves of 64 x 64)   1: 64 x 256 (4 waves)   2: 128 x 256 (8 waves)   3: 64 x 128 (2 waves)
 //   4:  32 x 256 (4 waves of 32 x 64)   5: 32 x 128 (2 waves)
 constexpr int kNumBf3Tiles = 8;      // 6 / 7 (round 3): a wave owns 32 rows x 128 columns -- no two waves of a workgroup fetch the same weight rows
-static bool h2_tile(int tile) { return tile == 0 || tile == 3 || tile == 4 || tile == 20 || tile == 22 || tile == 23 || tile == 6 || tile == 8 || tile == 14; }   // built for MATH 1
+static bool h2_tile(int tile) { return tile == 0 || tile == 3 || tile == 4 || tile == 20 || tile == 22 || tile == 23 || tile == 24; }   // built for MATH 1
 static bool bf3_tile_ok(int tile) { return (tile >= 0 && tile < kNumBf3Tiles) || (tile >= 8 && tile < 8 + kNumBf3Tiles) || (tile >= 20 && tile < 25); }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
@@ -955,7 +966,7 @@ bool conv_bf3_eligible(const ConvArgs& a) {
 // (the staged window is split once) when that still yields >= 2 workgroups per CU; a grid-starved launch (the
 // 256-channel stage of one utterance: 252 such tiles) takes 32-row x 256-column tiles instead (4x the workgroups,
 // 3 waves per SIMD).
-static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed = false) {
+static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed = false, int math = 0) {
     // units = utterances x group members x phases
     // (a polyphase transposed conv stages the same window once per phase and row block: always the tallest tile)
     if (transposed) {
@@ -967,6 +978,10 @@ static int pick_bf3_tile(int Cout_pad, long max_n, long units, bool transposed =
     }
     if (Cout_pad % 128 == 0) {
         const long n128 = (max_n + 127) / 128 * (Cout_pad / 128) * units;
+        // two-term fp16: with the matrix time halved, a grid of about one 128 x 128 tile per CU (the 256-channel stage of one
+        // utterance: 252) does better as 8-wave workgroups that split K between two wave groups (two waves per SIMD from one
+        // workgroup) than as 504 four-wave workgroups of 32 x 256: -3 % of the trunk (STS_BF3_GROUP_TILE sweep, round 3)
+        if (math == 1 && n128 >= 192 && n128 < 512) return 20;
         return n128 >= 512 ? 0 : 4;
     }
     if (Cout_pad % 64 == 0) return 3;
@@ -980,8 +995,9 @@ static constexpr size_t bf3_lds_bytes() {
     return stage > xchg ? stage : xchg;
 }
 
-// H2: this tile is also built for the two-term fp16 arithmetic (the tiles the automatic choice uses; conv_bf3 / conv_bf3_group
-// send a MATH 1 conv to no other)
+// H2: this tile is also built for the two-term fp16 arithmetic (the tiles the automatic choice uses plus 24; conv_bf3 /
+// conv_bf3_group send a MATH 1 conv to no other.  Round 3's sweep of the rest under MATH 1 -- 32 x 128 per wave, 32-channel
+// chunks, 64-row tiles -- found nothing better: profiles/r03_f16x2_tile_sweep.log)
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, bool H2 = false>
 static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st, int pm = 0) {
     constexpr int MT = 32 * MW * WM, NT = 32 * NW * WN;
@@ -1033,7 +1049,7 @@ void conv_bf3_stage(const StageArgs& A, hipStream_t st) {
 
 long conv_bf3_blocks(const ConvArgs& a) {
     const int nphase = a.transposed ? a.out_stride : 1;
-    const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
+    const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
     const int mt = tile == 4 ? 32 : (tile == 3 ? 64 : 128), nt = tile == 4 ? 256 : 128;
     return (long)((a.max_n + nt - 1) / nt) * ((a.Cout_pad + mt - 1) / mt) * nphase * a.B;
 }
@@ -1041,12 +1057,12 @@ long conv_bf3_blocks(const ConvArgs& a) {
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     const int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
-    if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0);
+    if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
     switch (tile) {
         case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         // phase-merged rows (transposed convs): 21: 256 x 128 (8 waves)   22: 128 x 128   23: 64 x 128 as two 32-row waves x 2
-        case 24: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 4, 1, 2, 2>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1>(a, nphase, st); break;
+        case 24: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 4, 1, 2, 2, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         case 21: launch_bf3<2, 2, 4, 2, 1>(a, nphase, st, 1); break;
         case 22: launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st, 1); break;
         case 23: launch_bf3<1, 2, 2, 2, 1, 1, true>(a, nphase, st, 1); break;
@@ -1056,11 +1072,11 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
         case 3: launch_bf3<2, 2, 1, 2, 1, 1, true>(a, nphase, st); break;
         case 4: launch_bf3<1, 2, 1, 4, 1, 1, true>(a, nphase, st); break;
         case 5: launch_bf3<1, 2, 1, 2, 1>(a, nphase, st); break;
-        case 6: launch_bf3<1, 4, 4, 1, 1, 1, true>(a, nphase, st); break;      // 128 x 128, four waves of 32 x 128
+        case 6: launch_bf3<1, 4, 4, 1, 1>(a, nphase, st); break;      // 128 x 128, four waves of 32 x 128
         case 7: launch_bf3<1, 4, 2, 1, 1>(a, nphase, st); break;      //  64 x 128, two waves of 32 x 128
-        case 14: launch_bf3<1, 4, 4, 1, 2, 1, true>(a, nphase, st); break;
+        case 14: launch_bf3<1, 4, 4, 1, 2>(a, nphase, st); break;
         case 15: launch_bf3<1, 4, 2, 1, 2>(a, nphase, st); break;
-        case 8: launch_bf3<2, 2, 2, 2, 2, 1, true>(a, nphase, st); break;
+        case 8: launch_bf3<2, 2, 2, 2, 2>(a, nphase, st); break;
         case 9: launch_bf3<2, 2, 1, 4, 2>(a, nphase, st); break;
         case 10: launch_bf3<2, 2, 2, 4, 2>(a, nphase, st); break;
         case 11: launch_bf3<2, 2, 1, 2, 2>(a, nphase, st); break;
@@ -1088,13 +1104,13 @@ void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
             ConvArgs t = G.g[j]; G.g[j] = G.g[j - 1]; G.g[j - 1] = t;
         }
     const ConvArgs& a = G.g[0];
-    if (!bf3_tile_ok(tile) || (a.math == 1 && (!h2_tile(tile) || tile >= 20))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n);
+    if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n, false, a.math);
     if (tile >= 8 && tile < 16) for (int i = 0; i < G.n; i++) if (G.g[i].Cin_pad % 32 != 0) { tile -= 8; break; }
     switch (tile) {
         case 20: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
-                   if (ok) launch_bf3_group<2, 2, 2, 2, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
+                   if (ok) launch_bf3_group<2, 2, 2, 2, 2, 2, true>(G, st); else launch_bf3_group<2, 2, 2, 2, 1, 1, true>(G, st); break; }
         case 24: { bool ok = true; for (int i = 0; i < G.n; i++) ok = ok && G.g[i].Cin_pad % 32 == 0;
-                   if (ok) launch_bf3_group<2, 2, 4, 1, 2, 2>(G, st); else launch_bf3_group<2, 2, 2, 2, 1>(G, st); break; }
+                   if (ok) launch_bf3_group<2, 2, 4, 1, 2, 2, true>(G, st); else launch_bf3_group<2, 2, 2, 2, 1, 1, true>(G, st); break; }
         case 0: launch_bf3_group<2, 2, 2, 2, 1, 1, true>(G, st); break;
         case 1: launch_bf3_group<2, 2, 1, 4, 1>(G, st); break;
         case 2: launch_bf3_group<2, 2, 2, 4, 1>(G, st); break;
