@@ -599,6 +599,7 @@ def main():
                 "peak": peak_tf,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / peak_tf,
+                "achieved_vs_split_bf16_peak": (achieved_tf / (PEAK_BF16_MFMA_TFLOPS / BF16_PRODUCTS_PER_F32)) if split else None,   # rounds 2 / 3 before f16x2 priced against 416.7
                 "peak_definition": (f"bf16 / fp16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TF/s / {products} 16-bit products per fp32 product "
                                     "(MI355X_MICROARCH.md; the exact-fp32 MFMA peak is 157.3)") if split else
                                    "v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)",
