@@ -205,24 +205,29 @@ def parity_report(ref_out, gpu_out):
 
 
 def measured_mfma_ceiling(products: int = BF16_PRODUCTS_PER_F32):
-    """Runs tools/ubench/libsts_ubench.so (a bare loop of conv_bf3.hip's 24-MFMA sequence) in THIS process on operands with
-    split-fp32 statistics and on constant operands: what the matrix pipe sustains on this box, now (data-dependent DVFS)."""
+    """Runs tools/ubench/libsts_ubench.so (a bare loop of conv_bf3.hip's MFMA sequence) in THIS process on operands with the
+    statistics of the kernel's own (split fp32 values: three bf16 planes / six products, or the two-term fp16 planes / three
+    products) and on constant operands: what the matrix pipe sustains on this box, now (data-dependent DVFS)."""
     import ctypes
     path = os.path.join(ROOT, "tools", "ubench", "libsts_ubench.so")
     if not os.path.exists(path):
         return None
     try:
         lib = ctypes.CDLL(path)
-        lib.sts_ubench_mfma_bf16.restype = ctypes.c_double
-        lib.sts_ubench_mfma_bf16.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        split = float(lib.sts_ubench_mfma_bf16(2, 512, 20000))      # ~20 ms
-        const = float(lib.sts_ubench_mfma_bf16(0, 512, 20000))
+        h2 = products == 3 and hasattr(lib, "sts_ubench_mfma_f16")
+        fn = lib.sts_ubench_mfma_f16 if h2 else lib.sts_ubench_mfma_bf16
+        fn.restype = ctypes.c_double
+        fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        n = 40000 if h2 else 20000                                  # ~20 ms
+        split = float(fn(2, 512, n))
+        const = float(fn(0, 512, n))
         if split <= 0:
             return None
-        return {"bf16_tflops_split_fp32_operands": split, "bf16_tflops_constant_operands": const,
+        kind = "fp16" if h2 else "bf16"
+        return {f"{kind}_tflops_split_fp32_operands": split, f"{kind}_tflops_constant_operands": const,
                 "tflops_fp32_equivalent": split / products,
-                "source": "tools/ubench/mfma_bf16_peak.hip run in this process right after the timed legs: 512 workgroups x 4 waves, "
-                          "20 000 x 24 v_mfma_f32_32x32x16_bf16 per wave (~20 ms)"}
+                "source": f"tools/ubench/mfma_bf16_peak.hip run in this process right after the timed legs: 512 workgroups x 4 waves, "
+                          f"{n} x {4 * products} v_mfma_f32_32x32x16_{'f16' if h2 else 'bf16'} per wave (~20 ms), operands = the kernel's own planes of random fp32 values"}
     except Exception:
         return None
 

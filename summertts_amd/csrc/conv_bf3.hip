@@ -61,9 +61,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //                 (the K loop is not waiting for weights)
 //   STS_H2_WAVES / STS_H2_MINW   most / fewest waves per SIMD the register budget is sized for.  3 / 3 (168 registers, three
 //                 128 x 128 workgroups per CU): +1 % / -2 %
-// tools/h2_decomp.sh (steps with the MFMAs / LDS reads / weight loads compiled out, profiles/r03_f16x2_kloop_decomposition.log): two
-// workgroups per CU spend ~1 070 cycles per 12-MFMA step = the pipe 72 % busy in the K loop (split-bf16: 1 650 per 24 = 93 %);
-// without the weight loads 917, without the LDS reads 1 030.
+//   (removed again) steps handled in pairs -- operands of steps s + 2, s + 3 requested, then 24 MFMAs back to back, rings of 4: no effect
+// tools/h2_decomp.sh / h2_decomp2.sh (parts of a step compiled out, profiles/r03_f16x2_kloop_decomposition.log): two workgroups per CU
+// spend ~1 070 cycles per 12-MFMA step = the pipe 72 % busy in the K loop (split-bf16: 1 650 per 24 = 93 %).  With nothing but the
+// MFMAs and the loop bookkeeping left: 760-810 (the pipe's own rate with two waves per SIMD; ONE wave per SIMD needs 632 -- its
+// bookkeeping does not overlap its own MFMAs).  The other ~280 cycles are the step's memory operations, none of them dominant:
+// weight loads 150, staging loads 80, LDS reads 40, barriers 15-40 -- 0.67 KB of operands per MFMA against split-bf16's 0.5, through
+// the same vector-memory and LDS pipes in half the time.  Prefetch depth, occupancy and burst length do not change that; a larger
+// tile per wave (fewer operand bytes per MFMA) would, and needs the accumulators in AGPRs at one wave per SIMD: not built.
 #ifndef STS_H2_AR
 #define STS_H2_AR 2
 #endif
