@@ -925,7 +925,11 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
         const size_t n = (size_t)nphase * ntap * Cin_pad * Cout_pad;
         for (size_t i = 0; i < n; i++) { const float v = wp[i] < 0.f ? -wp[i] : wp[i]; if (v > mx) mx = v; }
         int e = 0;
-        if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); up = ldexpf(1.0f, 14 - e); }    // mx = f * 2^e, f in [0.5, 1)
+        if (mx > 0.f && mx < 3.0e38f) {                         // mx = f * 2^e, f in [0.5, 1)
+            (void)frexpf(mx, &e);
+            const int s = 14 - e;
+            up = ldexpf(1.0f, s > 100 ? 100 : (s < -100 ? -100 : s));    // (a conv of vanishing weights: keep the scale and its inverse finite)
+        }
         if (wscale) *wscale = 1.0f / up;
     }
     for (int ph = 0; ph < nphase; ph++)

@@ -150,6 +150,9 @@ def test_f16x2_conv_against_float64(case):
         y = engine.debug_conv1d((x * np.float32(sx)).astype(np.float32), (w * np.float32(sw)).astype(np.float32), zero, pad, dil, st, dw, mode=50)
         rel = np.sqrt(np.mean((y / (sx * sw) - base) ** 2)) / rms
         assert rel <= tol, (case, sx, sw, rel)
+    # a conv of vanishing weights (max |w| ~ 2^-105: the per-conv scale is capped at 2^100) stays finite and accurate
+    y = engine.debug_conv1d(x, (w * np.float32(2.0 ** -100)).astype(np.float32), zero, pad, dil, st, dw, mode=50)
+    assert np.isfinite(y).all() and np.sqrt(np.mean((y.astype(np.float64) * 2.0 ** 100 - base) ** 2)) / rms <= 1e-5
     # fused input leaky-relu is applied before the split
     y = engine.debug_conv1d(x, w, b, pad, dil, st, dw, in_slope=0.1, in_act=1, mode=50)
     y1 = engine.debug_conv1d(np.where(x < 0, x * np.float32(0.1), x).astype(np.float32), w, b, pad, dil, st, dw, mode=50)
