@@ -117,6 +117,7 @@ int sts_set_conv_mode(sts_engine* e, int mode);
  *       fp16 MFMA products per fp32 product -- half the matrix-pipe time of 0, 22-23 instead of 24 operand bits (measured error
  *       against float64: DESIGN.md 5f) -- the default.  An activation beyond fp16's range raises a flag and the call (a
  *       streaming call: the chunk, before it is handed out) is repeated in form 0; sts_profile.conv_math_fallbacks counts these.
+ *       After two such calls in a row the engine stays in form 0 until sts_set_conv_math is called again.
  *   The default can also be chosen with the environment variable STS_CONV_MATH = f16x2 | bf16x3 | f32. */
 int sts_set_conv_math(sts_engine* e, int mode);
 

@@ -142,6 +142,7 @@ int sts_set_conv_math(sts_engine* e, int mode) {
     if (!e) return set_err(STS_EINVAL, "null engine");
     if (mode < 0 || mode > 3) return set_err(STS_EINVAL, "conv math: 0 = split-bf16 (default), 1 = exact fp32, 2 = split-bf16 wherever eligible, 3 = two-term fp16");
     e->eng.conv_math = mode;
+    e->eng.h2_consecutive = 0; e->eng.h2_disabled = false;
     return STS_OK;
 }
 int sts_set_conv_mode(sts_engine* e, int mode) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.conv_mode = mode; return STS_OK; }

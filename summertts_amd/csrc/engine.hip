@@ -1241,8 +1241,16 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
 // depend on the flag being rare.  A streaming call checks the word before each chunk leaves: raised during the first chunk (or
 // before it: text encoder, flow) the call starts over, later only that chunk is decoded again -- split-bf16 from there on.
 static constexpr int kRetrySplitBf16 = 1;     // run_once: nothing was handed out, repeat in the split-bf16 form
+// An engine that had to repeat two calls in a row stays in the split-bf16 form (a model whose activations do not fit fp16 would
+// otherwise pay for both forms on every call) until sts_set_conv_math is called again.
 int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_t* sid, const float* ls, const StreamSpec* ss) {
     if (conv_math != 3) return run_once(B, ids, n, sid, ls, ss);
+    if (h2_disabled) {
+        conv_math = 0;
+        const int rc0 = run_once(B, ids, n, sid, ls, ss);
+        conv_math = 3;
+        return rc0;
+    }
     HIPCK(hipSetDevice(device));
     if (!ovf_host_) {
         if (hipHostMalloc((void**)&ovf_host_, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&ovf_, ovf_host_, 0) != hipSuccess) {
@@ -1253,6 +1261,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     }
     *(volatile unsigned*)ovf_host_ = 0u;
     const bool forced = have_forced;          // (a run consumes the forced durations: the repeat needs them again)
+    const long before = h2_fallbacks;
     int rc = run_once(B, ids, n, sid, ls, ss);
     if ((rc == STS_OK && !ss && *(volatile unsigned*)ovf_host_ != 0u) || rc == kRetrySplitBf16) {
         h2_fallbacks++;
@@ -1261,6 +1270,7 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
         rc = run_once(B, ids, n, sid, ls, ss);
     }
     conv_math = 3;
+    if (h2_fallbacks != before) { if (++h2_consecutive >= 2) h2_disabled = true; } else h2_consecutive = 0;
     return rc;
 }
 

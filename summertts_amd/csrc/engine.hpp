@@ -72,6 +72,7 @@ public:
     int conv_mode = 0;
     int conv_math = 3;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA, 3 = two-term fp16 (sts_set_conv_math)
     long h2_fallbacks = 0;             // runs repeated in split-bf16 because an activation left fp16's range (conv_math 3)
+    int h2_consecutive = 0; bool h2_disabled = false;   // two repeats in a row: the engine stays on split-bf16 until sts_set_conv_math
     double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
     bool pk_trace = false;             // record the persistent kernel's per-op timeline into taps["pk_trace"] (sts_debug_set)

@@ -194,13 +194,18 @@ def test_f16x2_falls_back_when_an_activation_leaves_the_fp16_range():
     assert np.array_equal(syn.pcm_host(), want)
     syn.run_batch([ids])
     assert syn.profile()["conv_math_fallbacks"] == 2
+    # two repeats in a row: the engine stops trying (no third repeat, same result) until the setting is made again
+    syn.set_forced_durations([3] * len(ids))
+    syn.run_batch([ids])
+    assert syn.profile()["conv_math_fallbacks"] == 2
+    assert np.array_equal(syn.pcm_host(), want)
     # streaming: the word is checked before the first chunk leaves -- the call starts over in the split-bf16 form
     syn.set_conv_math("bf16x3")
     syn.set_forced_durations([3] * len(ids))
     ref_chunks, _ = syn.infer_ids_stream(ids, 16)
     syn.set_conv_math("f16x2")
     syn.set_forced_durations([3] * len(ids))
-    chunks, _ = syn.infer_ids_stream(ids, 16)
+    chunks, _ = syn.infer_ids_stream(ids, 16)          # (set_conv_math above re-armed the two-term form)
     assert syn.profile()["conv_math_fallbacks"] == 3
     assert np.array_equal(np.concatenate(chunks), np.concatenate(ref_chunks))
     syn.close()
