@@ -130,3 +130,33 @@ def test_multi_device_gather_layout_and_flag_validation(lib):
     h = C.c_void_p()
     dev = np.zeros(1, np.int32)
     assert lib.sts_multi_create_ex(blob.ctypes.data, blob.nbytes, dev.ctypes.data, 1, 7, C.byref(h)) < 0      # unknown flags
+
+
+def _header_struct_fields(name):
+    """(type, field) pairs of `typedef struct <name> { ... } <name>;` in include/summertts_hip.h, in declaration order."""
+    src = open(os.path.join(ROOT, "include", "summertts_hip.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        out += [(ctype, n.strip()) for n in names.split(",")]
+    return out
+
+
+@pytest.mark.parametrize("cname, mirror", [("sts_profile", engine.Profile), ("sts_model_info", engine.ModelInfo)])
+def test_python_struct_mirrors_match_the_header(cname, mirror, tmp_path):
+    """The ctypes mirrors of the ABI structs (summertts_amd/engine.py) name the header's fields in the header's order with the
+    header's types, and have the size the C compiler gives the struct -- a field appended on one side only (round 3 added
+    conv_math_fallbacks) would silently shift every later read."""
+    ctypes_of = {"float": C.c_float, "double": C.c_double, "int32_t": C.c_int32, "int64_t": C.c_int64}
+    want = [(n, ctypes_of[t]) for t, n in _header_struct_fields(cname)]
+    assert [(n, t) for n, t in mirror._fields_] == want
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include <stdio.h>\n#include "summertts_hip.h"\nint main(void) { printf("%%zu", sizeof(%s)); return 0; }\n' % cname)
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    assert int(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout) == C.sizeof(mirror)
