@@ -329,6 +329,13 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pk_flow_kernel(PkFlowArgs A_) {
                     __syncthreads();
                     if (tid == 0) __hip_atomic_fetch_add(&done[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (trace && tid == 0) { trace[s * 8 + 1] = (long long)__builtin_amdgcn_s_memtime(); trace[s * 8 + 3] = (long long)(x * 1000 + chunk + 1); }
+                } else {
+                    // nothing to do for this workgroup (its claim was beyond the op's chunks): thread 0 must not publish the next
+                    // chunk before every wave has read this one and the "more" word of the round before.  Without this barrier a
+                    // workgroup that starts late and runs through ops that are already complete (several engines sharing the GPU)
+                    // let its slower waves read thread 0's NEXT pair of words: a chunk processed twice, an op counted complete
+                    // early, one wrong window in ~1 of 50 calls (tools/concurrent_engines_check.py)
+                    __syncthreads();
                 }
                 // while the op completes elsewhere: pull this workgroup's share of the NEXT op's weights into the XCD's L2
                 if (!warmed && s + 1 < nsteps) { pk_warm(sprog[s + 1], rank, tid, sink); warmed = true; }

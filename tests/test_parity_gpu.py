@@ -886,13 +886,11 @@ def test_multi_device_rccl_gather_with_a_one_rank_communicator():
 def test_persistent_flow_kernels_of_several_engines_do_not_deadlock():
     """persist.hip never waits for a workgroup that is not resident: three engines on ONE GPU run their persistent flow kernels
     (256 workgroups x 16 waves each -- one alone fills the chip) from three host threads at the same time, twenty calls each; a
-    barrier-style kernel would hang as soon as two of them interleave.  Afterwards every engine, called alone, must return the
-    single-engine result (no counter or buffer is left in a bad state).
-    KNOWN DEFECT of this opt-in path (round 3, tools/concurrent_engines_check.py): while the kernels of several engines
-    interleave, about 1 call in 50 returns one wrong window of the frame axis (an acquire fence after the completion wait does not
-    cure it -- not a stale-L1 effect; the suspect is the re-claim path that only runs when workgroups are not resident).  The
-    default path (front_mode 0 / 1) is exact under the same load; the persistent kernel stays opt-in.  A mismatch in the
-    concurrent phase is therefore reported as an expected failure, a hang or a bad state afterwards as a failure."""
+    barrier-style kernel would hang as soon as two of them interleave.  Every call must return the single-engine result -- this
+    is the load under which a workgroup starts late and runs through ops that are already complete, the path on which round 3
+    found thread 0 publishing the next chunk before the slower waves had read the current one (one wrong window in ~1 of 50
+    calls; fixed by a barrier on the nothing-to-do path, tools/concurrent_engines_check.py: 0 of 480 since) -- and the default
+    per-layer path is checked under the same load."""
     import threading
     cfg = sb.full_cfg("hifigan_sdp")
     blob = sb.make_blob(cfg, 1234)
@@ -938,8 +936,7 @@ def test_persistent_flow_kernels_of_several_engines_do_not_deadlock():
     assert not bad_default, bad_default
     for e in engines:
         e.close()
-    if bad:
-        pytest.xfail(f"known defect of the opt-in persistent flow kernel under concurrent engines: {len(bad)} of 60 calls differ {bad[:4]}")
+    assert not bad, f"persistent flow kernel under concurrent engines: {len(bad)} of 60 calls differ {bad[:4]}"
 
 
 def test_persistent_decoder_stage_kernel_matches_the_grouped_launches():
