@@ -576,8 +576,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": (("f32 (decoder trunk convs: fp32 operands as 2 fp16 terms, 3 fp16 MFMA products per fp32 product, f32 accumulation; "
-                       "everything else f32)") if args.conv_math == "f16x2" else
+            "dtype": (("f32 (decoder trunk convs: fp32 operands as 2 fp16 terms = 22-23 of their 24 mantissa bits, 3 fp16 MFMA products per fp32 "
+                       "product, f32 accumulation -- measured error in `parity`, same tolerance as the exact-fp32 leg; everything else f32)")
+                      if args.conv_math == "f16x2" else
                       ("f32 (decoder trunk convs: fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, "
                        "f32 accumulation; everything else f32)")) if split else "f32",
             "data": "synthetic (seeded random weights in the reference .bin grammar; ids[i]=(i*37+11) mod vocab); the reference's "
