@@ -123,12 +123,30 @@ def main():
             return f"{np.mean(r):.0f} bf16 TF/s = {np.mean(r) / 6:.0f} fp32-equivalent"
         return f
 
+    def ubh(mode):
+        lib.sts_ubench_mfma_f16.restype = ctypes.c_double
+        lib.sts_ubench_mfma_f16.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+
+        def f(sec):
+            t0, r = time.perf_counter(), []
+            while time.perf_counter() - t0 < sec:
+                r.append(lib.sts_ubench_mfma_f16(mode, 512, 400000))        # ~0.2 s per call
+            return f"{np.mean(r):.0f} fp16 TF/s = {np.mean(r) / 3:.0f} fp32-equivalent"
+        return f
+
+    if os.environ.get("POWER_TRACE_SHORT"):      # the phases that changed with the two-term fp16 default (round 3)
+        s.phase("idle", idle, 1.0)
+        s.phase("synthesis step, batch 1 (128 phonemes), default arithmetic", synth(1), secs)
+        s.phase("synthesis step, batch 8 (64..256 phonemes), default arithmetic", synth(8), secs)
+        s.phase("bare fp16 MFMA loop, two-term planes of random fp32", ubh(2), secs)
+        return
     s.phase("idle", idle, 2.0)
     s.phase("synthesis step, batch 1 (128 phonemes)", synth(1), secs)
     s.phase("synthesis step, batch 8 (64..256 phonemes)", synth(8), secs)
     s.phase("bare MFMA loop, constant operands", ub(0), secs)
     s.phase("bare MFMA loop, random bf16 operands", ub(1), secs)
     s.phase("bare MFMA loop, hi/mid/lo planes of random fp32", ub(2), secs)
+    s.phase("bare fp16 MFMA loop, two-term planes of random fp32", ubh(2), secs)
     s.phase("idle", idle, 2.0)
 
 
