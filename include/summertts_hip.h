@@ -117,15 +117,19 @@ int sts_set_conv_mode(sts_engine* e, int mode);
  *       fp16 MFMA products per fp32 product -- half the matrix-pipe time of 0, 22-23 instead of 24 operand bits (measured error
  *       against float64: DESIGN.md 5f) -- the default.  An activation beyond fp16's range raises a flag and the call (a
  *       streaming call: the chunk, before it is handed out) is repeated in form 0; sts_profile.conv_math_fallbacks counts these.
- *       After two such calls in a row the engine stays in form 0 until sts_set_conv_math is called again.
- *   The default can also be chosen with the environment variable STS_CONV_MATH = f16x2 | bf16x3 | f32. */
+ *       After two such calls in a row the engine stays in form 0 until sts_set_conv_math is called again
+ *       (sts_profile.conv_math_pinned).  The first repeat of an engine and the pinning are reported through tts_log.
+ *   The default can also be chosen with the environment variable STS_CONV_MATH = f16x2 | bf16x3 | f32; any other value is
+ *   reported through tts_log and ignored (the default applies). */
 int sts_set_conv_math(sts_engine* e, int mode);
 
 /*   test hooks (per engine, never read from the environment): force a kernel family that the automatic choice would not pick
  *   at the size of a test.  key: STS_DBG_ATTN_BLOCK_MIN_WGS -- the matrix-core block attention kernel engages from this many
- *   workgroups on (default 96; 1 = always);  STS_DBG_FRONT_MODE -- the reverse flow of a one-utterance call:
- *   0 = automatic (today: one launch per layer), 1 = always one launch per layer, 2 = the persistent single-launch kernel of
- *   persist.hip (one window of the frame axis per XCD) whenever the model is eligible. */
+ *   workgroups on (default 96; 1 = always).
+ *   STS_DBG_FRONT_MODE / STS_DBG_TRUNK_MODE / STS_DBG_PK_TRACE select the two persistent-kernel families of round 3 (persist.hip,
+ *   conv_bf3_stage_kernel).  Both lost their A/B against the launch path, so they exist only in the lab build
+ *   (`make -C summertts_amd/csrc exp`, -DSTS_EXPERIMENTS); the shipped library accepts the values that mean "the launch path"
+ *   (0, 1) and answers STS_EINVAL to 2. */
 enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2, STS_DBG_PK_TRACE = 3 /* per-op timeline of the persistent kernel -> tap "pk_trace" */,
        STS_DBG_TRUNK_MODE = 4 /* 128-channel decoder stage of a one-utterance call: 0 automatic, 1 grouped launches, 2 one persistent launch per stage */ };
 int sts_debug_set(sts_engine* e, int key, int value);
@@ -146,9 +150,21 @@ typedef struct sts_profile {
     double flops_decoder_bf16_issued;     /* bf16 matrix-core FLOPs issued by the timed launches that run on split operands
                                              (6 x their algorithmic FLOPs; 3 x with sts_set_conv_math(3)); 0 with sts_set_conv_math(1) */
     int64_t conv_math_fallbacks;          /* sts_set_conv_math(3): calls of this engine so far that were repeated in the split-bf16 form */
+    int32_t conv_math_pinned;             /* 1: after two such calls in a row the engine now stays in the split-bf16 form (until sts_set_conv_math) */
+    int32_t reserved0;
 } sts_profile;
 int sts_set_profiling(sts_engine* e, int enable);
+/* The struct only ever grows at its end (STS_ABI_VERSION counts the revisions).  sts_get_profile_ex copies min(size_bytes,
+ * sizeof(sts_profile)) bytes, so a client compiled against an older header passes ITS sizeof and is never overrun;
+ * sts_get_profile(e, p) == sts_get_profile_ex(e, p, sizeof(sts_profile)) of the header this library was built from -- use it only
+ * when client and library are built together. */
+#define STS_ABI_VERSION 4
+int sts_abi_version(void);
+/* bit 0: lab build (-DSTS_EXPERIMENTS: environment knobs of knobs.hpp, the persistent-kernel families, every conv tile code);
+ * 0 for the shipped library */
+int sts_build_flags(void);
 int sts_get_profile(const sts_engine* e, sts_profile* p);
+int sts_get_profile_ex(const sts_engine* e, void* p, int64_t size_bytes);
 
 /* Stand-alone conv entry for op-level parity tests: y = conv1d(x) with x [Cin][L] on the host.
  * w is the reference layout [out][k][in] (transposed: same).  mode as sts_set_conv_mode; 13 / 20.. = the split-bf16 kernel
@@ -195,14 +211,20 @@ const char* sts_pool_last_error(void);
  * The handle is not re-entrant (one batch at a time), like an engine. */
 typedef struct sts_multi sts_multi;
 int sts_multi_create(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, sts_multi** out);
-/*   How the PCM comes home.  STS_MULTI_AUTO (= sts_multi_create): the RCCL gather when the devices are distinct and more than
- *   one, the per-device PCIe download otherwise (or when librccl cannot be loaded).  STS_MULTI_RCCL: one RCCL communicator rank
- *   per device (ncclCommInitAll; distinct devices required, one is allowed): sample counts by ncclAllGather, the int16 PCM of
- *   ranks > 0 by ncclSend / grouped ncclRecv into a gather buffer on devices[0] (over xGMI), then ONE download.
- *   STS_MULTI_DOWNLOAD: every device downloads its own shard.  sts_multi_gather_mode reports which one a handle uses (1 = RCCL). */
+/*   How the PCM comes home.  STS_MULTI_AUTO (= sts_multi_create) and STS_MULTI_DOWNLOAD: every device downloads its own shard over
+ *   PCIe.  STS_MULTI_RCCL (opt-in): one RCCL communicator rank per device (ncclCommInitAll; distinct devices required, one is
+ *   allowed): sample counts and a "rank 0 can receive" word by ncclAllGather, the int16 PCM of ranks > 0 by ncclSend / grouped
+ *   ncclRecv into a gather buffer on devices[0] (over xGMI), then ONE download.  A failure or a 60 s timeout inside a collective
+ *   aborts all communicators of the handle (ncclCommAbort): that call returns STS_EDEVICE -- it never hangs -- and the handle
+ *   continues with per-device downloads.  The RCCL path is not part of the automatic mode because it has not been run on N > 1 real
+ *   devices yet.  sts_multi_gather_mode reports which one a handle uses (1 = RCCL). */
 enum { STS_MULTI_AUTO = 0, STS_MULTI_RCCL = 1, STS_MULTI_DOWNLOAD = 2 };
 int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, int32_t flags, sts_multi** out);
 int sts_multi_gather_mode(const sts_multi* m);
+/*   test hook: the shared library that provides the nccl* entry points (NULL / "" = librccl.so.1) and whether STS_MULTI_RCCL may list
+ *   one device several times (tests/fake_rccl: N emulated ranks on one GPU; real RCCL refuses duplicates).  Only before the first
+ *   STS_MULTI_RCCL handle of the process is created. */
+int sts_multi_set_rccl_library(const char* path, int allow_repeated_devices);
 /*   layout of the gather buffer (host arithmetic only): rank r's block starts at offsets[r] samples (256-byte aligned);
  *   returns the buffer's extent in samples */
 int64_t sts_multi_gather_layout(const int64_t* counts, int32_t n_ranks, int64_t* offsets);

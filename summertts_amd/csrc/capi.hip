@@ -150,20 +150,38 @@ int sts_debug_set(sts_engine* e, int key, int value) {
     if (!e) return set_err(STS_EINVAL, "null engine");
     switch (key) {
         case STS_DBG_ATTN_BLOCK_MIN_WGS: if (value < 1) return set_err(STS_EINVAL, "threshold must be >= 1"); e->eng.attn_block_min_wgs = value; return STS_OK;
+#ifdef STS_EXPERIMENTS
         case STS_DBG_FRONT_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "front mode must be 0, 1 or 2"); e->eng.front_mode = value; return STS_OK;
         case STS_DBG_TRUNK_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "trunk mode must be 0, 1 or 2"); e->eng.trunk_mode = value; return STS_OK;
         case STS_DBG_PK_TRACE: e->eng.pk_trace = value != 0; return STS_OK;
+#else
+        // the persistent-kernel families exist only in the lab build (`make -C summertts_amd/csrc exp`): the shipped library has one path
+        case STS_DBG_FRONT_MODE: case STS_DBG_TRUNK_MODE: case STS_DBG_PK_TRACE:
+            if (value == 0 || (key != STS_DBG_PK_TRACE && value == 1)) return STS_OK;       // "automatic" / "the launch path": what this build always does
+            return set_err(STS_EINVAL, "this key selects a lab-only kernel family: build with -DSTS_EXPERIMENTS (make exp)");
+#endif
         default: return set_err(STS_EINVAL, "unknown debug key");
     }
 }
 int sts_set_host_pcm(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.host_pcm = enable != 0; return STS_OK; }
 int sts_set_profiling(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.profiling = enable != 0; return STS_OK; }
 
-int sts_get_profile(const sts_engine* e, sts_profile* p) {
-    if (!e || !p) return set_err(STS_EINVAL, "null argument");
-    *p = e->eng.prof;
+int sts_abi_version(void) { return STS_ABI_VERSION; }
+int sts_build_flags(void) {
+#ifdef STS_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+int sts_get_profile_ex(const sts_engine* e, void* p, int64_t size_bytes) {
+    if (!e || !p || size_bytes <= 0) return set_err(STS_EINVAL, "null argument");
+    // the struct only grows at its end: a client built against an older header hands in its own sizeof and gets that prefix
+    const size_t n = (size_t)size_bytes < sizeof(sts_profile) ? (size_t)size_bytes : sizeof(sts_profile);
+    memcpy(p, &e->eng.prof, n);
     return STS_OK;
 }
+int sts_get_profile(const sts_engine* e, sts_profile* p) { return sts_get_profile_ex(e, p, (int64_t)sizeof(sts_profile)); }
 
 int sts_get_tap(sts_engine* e, const char* name, float** data, int32_t* channels, int64_t* length) {
     if (!e || !name || !data || !channels || !length) return set_err(STS_EINVAL, "null argument");

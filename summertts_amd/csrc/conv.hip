@@ -1418,11 +1418,22 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
     for (int col = threadIdx.x; col < W; col += 256) {
         const int pos = n0 + a.tap_off + col;
         const bool ok = pos >= 0 && pos < in_len;
-        const float* xcol = a.x + in_base + (ok ? pos : 0);
+        const size_t coff = in_base + (ok ? pos : 0);
+        const float* xcol = a.x + coff;
         for (int c0 = 0; c0 < a.Cin; c0 += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) v[u] = (ok && c0 + u < a.Cin) ? xcol[(size_t)(c0 + u) * a.x_ld] : 0.f;
+            if (a.nsum >= 2) {      // the input is the mean of 2 / 3 tensors (ConvArgs::nsum), formed in sum_scale's order
+                float v1[8], v2[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v1[u] = (ok && c0 + u < a.Cin) ? a.xs1[coff + (size_t)(c0 + u) * a.x_ld] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; u++) v2[u] = (a.nsum > 2 && ok && c0 + u < a.Cin) ? a.xs2[coff + (size_t)(c0 + u) * a.x_ld] : 0.f;
+                const float div = (float)a.nsum;
+#pragma unroll
+                for (int u = 0; u < 8; u++) { float t = v[u] + v1[u]; if (a.nsum > 2) t += v2[u]; v[u] = t / div; }
+            }
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (c0 + u < a.Cin) {
@@ -1444,6 +1455,11 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
     if (a.bias) v += a.bias[0];
     if (a.ubias) v += a.ubias[b];
     epi_scalar(a, 0, out_base + (size_t)n, v);
+}
+
+bool conv_cout1_takes(const ConvArgs& a) {
+    if (!(a.Cout == 1 && !a.depthwise && !a.transposed && !a.in_reflect && a.tap_step > 0 && a.max_n >= 4096 && a.epi != EPI_GATE)) return false;
+    return ((size_t)a.Cin * (256 + (a.ntap - 1) * a.tap_step) + (size_t)a.ntap * a.Cin) * sizeof(float) <= 64 * 1024;
 }
 
 void conv_generic(const ConvArgs& a, hipStream_t st) {

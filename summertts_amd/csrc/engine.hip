@@ -6,6 +6,7 @@
 // data-dependent frame count F (SynthesizerTrn.cpp:376-381).
 #include "engine.hpp"
 #include "knobs.hpp"
+#include "../../include/tts_logger.h"
 
 #include <algorithm>
 #include <chrono>
@@ -32,12 +33,14 @@ Engine::~Engine() {
     if (ovf_host_) (void)hipHostFree(ovf_host_);
     if (hmap_) (void)hipHostFree(hmap_);
     if (arrive_) (void)hipFree(arrive_);
+#ifdef STS_EXPERIMENTS
     if (ps_priv_) (void)hipFree(ps_priv_);
     if (ps_tab_) (void)hipFree(ps_tab_);
     if (ps_tab_host_) (void)hipHostFree(ps_tab_host_);
     if (ps_ctr_) (void)hipFree(ps_ctr_);
     if (pk_prog_) (void)hipFree(pk_prog_);
     if (pk_ctr_) (void)hipFree(pk_ctr_);
+#endif
     if (have_events_) {
         for (auto& e : ev_) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_fork_);
@@ -48,6 +51,16 @@ Engine::~Engine() {
 }
 
 static int default_conv_math();
+// one polite spin-wait step on whatever host this is built for (the x86 builtin alone broke aarch64 / ppc64 builds)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 
 int Engine::init(const float* blob, int64_t bytes, int dev) {
     conv_math = default_conv_math();
@@ -107,8 +120,13 @@ void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); 
 // terms, six products) | f32 (the exact-fp32 MFMA instruction)          (conv_bf3.hip)
 static int default_conv_math() {
     const char* v = getenv("STS_CONV_MATH");
-    if (v && (!strcmp(v, "bf16x3") || !strcmp(v, "0"))) return 0;
-    return v && (!strcmp(v, "f32") || !strcmp(v, "fp32") || !strcmp(v, "1")) ? 1 : 3;
+    if (!v || !*v) return 3;
+    if (!strcmp(v, "f16x2") || !strcmp(v, "3")) return 3;
+    if (!strcmp(v, "bf16x3") || !strcmp(v, "0")) return 0;
+    if (!strcmp(v, "f32") || !strcmp(v, "fp32") || !strcmp(v, "1")) return 1;
+    // (a typo such as "bf16" used to select a default silently)
+    tts_log(TTS_LOG_WARNING, (std::string("summertts_hip: STS_CONV_MATH=") + v + " is not one of f16x2 | bf16x3 | f32 -- ignored, the default (f16x2) applies\n").c_str());
+    return 3;
 }
 
 ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o, double* flops) {
@@ -133,6 +151,7 @@ ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float
     a.epi = o.epi; a.epi_flag = o.epi_flag; a.epi_scale = o.epi_scale; a.H = c.H; a.gate_perm = c.gate_perm;
     a.in_seg = lin.seg; a.out_seg = lout.seg; a.B = lout.nb;
     a.kslices = o.kslices; a.kslice_stride = o.kslice_stride;
+    if (o.nsum >= 2) { a.xs1 = o.sum1; a.xs2 = o.sum2; a.nsum = o.nsum; }
     const double positions = c.transposed ? (double)lin.total : (double)lout.total;
     const double fl = 2.0 * c.macs_per_out * positions;
     flops_[cur_stage_] += fl;
@@ -148,12 +167,19 @@ ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float
 
 void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o) {
     double fl = 0;
-    const ConvArgs a = conv_args(c, x, lin, y, lout, o, &fl);
+    ConvArgs a = conv_args(c, x, lin, y, lout, o, &fl);
     const bool can_mfma = conv_mode != 1 && conv_mfma_eligible(a);
     // split-bf16 arithmetic: the decoder trunk always; other matrix-core convs (flow, text encoder, conv_pre) from the grid size on
     // at which they stop being launch-latency-bound (a batch of a few dozen utterances); conv_math 2 = wherever eligible (tests)
-    if (conv_mode == 0 && conv_math != 1 && o.tile < 0 && conv_bf3_eligible(a) &&
-        (in_mfma_region_ || conv_math == 2 || conv_bf3_blocks(a) >= 384)) {
+    const bool use_bf3 = conv_mode == 0 && conv_math != 1 && o.tile < 0 && conv_bf3_eligible(a) &&
+                         (in_mfma_region_ || conv_math == 2 || conv_bf3_blocks(a) >= 384);
+    if (a.nsum >= 2 && !(use_bf3 ? conv_bf3_takes_sum(a) : (!can_mfma && conv_cout1_takes(a)))) {
+        // this conv's kernel cannot form the mean of its input terms while staging: one launch materialises it (the round-3 form)
+        const float* r[3] = {x, o.sum1, o.sum2};
+        sum_scale(o.sum_dst, r, a.nsum, o.sum_n, cur_);
+        a.x = o.sum_dst; a.xs1 = a.xs2 = nullptr; a.nsum = 0;
+    }
+    if (use_bf3) {
         if (in_mfma_region_) { mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_++; }
         static const int bt = exp_int("STS_BF3_TILE", -1);   // experiment knob
         conv_bf3(a, cur_, bt);
@@ -262,6 +288,7 @@ float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv,
     return cur;
 }
 
+#ifdef STS_EXPERIMENTS   // lab build only: the persistent single-launch flow (persist.hip) lost to the launch-per-layer path
 // The reverse flow as ONE persistent launch (persist.hip): the op list of ResidualCouplingBlock.cpp:59-70 / ResidualCouplingLayer.cpp:47-66 /
 // WN.cpp:100-149 in execution order, every op annotated with the halo its output still needs (the receptive field of all the ops
 // behind it).  Static per model; built and uploaded on first use.
@@ -334,6 +361,7 @@ bool Engine::flow_program() {
     pk_state_ = 1;
     return true;
 }
+#endif  // STS_EXPERIMENTS
 
 void Engine::tap(const char* name, const float* d, int channels, long ld, long length) {
     if (!record_taps) return;
@@ -662,7 +690,7 @@ int Engine::run_durations(RunCtx& c) {
             // workers must not each burn a core for a whole batch --, and after 50 ms a plain stream synchronisation
             for (long spin = 0; ; spin++) {
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_) { ok = true; break; }
-                __builtin_ia32_pause();
+                cpu_relax();
                 if (spin >= 20000) std::this_thread::yield();
                 if ((spin & 0x3ff) == 0x3ff) {      // every ~1k polls: did the stream die?  (a kernel fault would spin forever)
                     const hipError_t q = hipStreamQuery(stream);
@@ -737,15 +765,22 @@ int Engine::run_frame_workspace(RunCtx& c) {
     // 0.44 ms for the 41 launches -- an op inside the persistent kernel still costs ~6 us of dependent latencies (claim, operand
     // round trips, partial-sum exchange, store acknowledgement, completion poll) and the gate convs are fp32-MFMA-bound on windows
     // that overlap 1.77x -- so the launch-per-layer path stays the default and this one is opt-in: front_mode 2 (sts_debug_set)
+#ifdef STS_EXPERIMENTS
     const bool use_pk = c.use_pk = B == 1 && !M.cp.empty() && front_mode == 2 && conv_mode == 0 && conv_math != 2 && Ftot <= 16384 && flow_program();
     const int pk_fs = c.pk_fs = (int)((Ftot + 7) / 8);
     const int pk_wld = c.pk_wld = (pk_fs + 2 * pk_halo_ + 31) / 32 * 32 + 32;
     const int pk_rows = c.pk_rows = C > wnH ? C : wnH;
+#else
+    const bool use_pk = c.use_pk = false;       // (the shipped library carries no persistent flow kernel)
+    const int pk_fs = 0, pk_wld = 0, pk_rows = 0;
+#endif
     BufF& bf = c.bf;
     auto layoutF = [&](Arena& A) {
         A.used = 0;
+#ifdef STS_EXPERIMENTS
         bf.pk = A.get<float>(use_pk ? (size_t)8 * 4 * pk_rows * pk_wld : 1);
         bf.pk_trace = A.get<long long>(use_pk && pk_trace ? (size_t)256 * PK_MAX_STEPS * 8 : 1);
+#endif
         bf.z = A.get<float>((size_t)C * Ftot); bf.h = A.get<float>((size_t)wnH * Ftot);
         bf.acts = A.get<float>((size_t)wnH * Ftot); bf.out = A.get<float>((size_t)wnH * Ftot);
         bf.fliptmp = A.get<float>((M.n_flows & 1) ? (size_t)C * Ftot : 1);
@@ -775,6 +810,7 @@ int Engine::run_flow(RunCtx& c) {
     // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
     stage_begin(2);
     const int half = C / 2;
+#ifdef STS_EXPERIMENTS
     if (use_pk) {
         if (record_taps) { expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream); tap("z_p", bf.z, C, Ftot, Ftot); }
         const long cstride = (long)((2 * wnH * wnL + 3) & ~3);
@@ -824,7 +860,9 @@ int Engine::run_flow(RunCtx& c) {
                 t.data[((size_t)wg * 8 + q) * PK_MAX_STEPS + s2] = q == 3 ? (float)v : (v ? (float)(v - t0[xcd[wg]]) : -1.f);
             }
         }
-    } else {
+    } else
+#endif
+    {
     expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream);
     tap("z_p", bf.z, C, Ftot, Ftot);
 
@@ -854,6 +892,7 @@ int Engine::run_flow(RunCtx& c) {
     return STS_OK;
 }
 
+#ifdef STS_EXPERIMENTS   // lab build only: a tie with the grouped launches
 // One decoder stage of one utterance as ONE persistent launch (conv_bf3_stage, kernels.hpp StageArgs): the time axis cut into a
 // window per XCD (own column tiles + one tile of halo per side), private per-XCD buffers for the chain intermediates, the stage's
 // final chain outputs written (own columns only) where the grouped launches would have put them.  Returns false when the stage is
@@ -974,6 +1013,7 @@ bool Engine::stage_persistent(RunCtx& c, int i, const float* bup, const Lvl& l2,
     ps_tab_busy_ = true;
     return true;
 }
+#endif  // STS_EXPERIMENTS
 
 // ---- stage 5: one decode pass over `nw` windows of z
 // ---------------- decoder trunk (Generator_hifigan.cpp:139-175 and the identical loops of MS/Istft/MBB)
@@ -1002,6 +1042,11 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
     const float* x = bf.x0;
     int S = 1;
     Lvl lx = lw1;
+    // the mean over a stage's ResBlock chains is not formed by a launch of its own: the conv that consumes it (the next upsampler, the
+    // output conv) adds the chains' outputs up while it stages its input window (ConvArgs::nsum), -4 launches / ~40 us per step
+    struct { const float* p[3] = {nullptr, nullptr, nullptr}; int n = 0; float* dst = nullptr; long count = 0; } mean;
+    auto with_mean = [&](ConvOpt& o) { if (mean.n >= 2) { o.sum1 = mean.p[1]; o.sum2 = mean.p[2]; o.nsum = mean.n; o.sum_dst = mean.dst; o.sum_n = mean.count; } };
+    static const bool no_sum_fold = exp_flag("STS_NO_SUM_FOLD");   // experiment knob
     mark(5);
     in_mfma_region_ = true;
     for (int i = 0; i < M.n_up; i++) {
@@ -1016,7 +1061,9 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
             static const char* ut = exp_env("STS_UP_TILE");
             if (ut && (int)strlen(ut) > i && ut[i] >= '0' && ut[i] <= '7') ou.tile = ut[i] - '0';
         }
+        with_mean(ou);
         conv(up, x, lx, bup, l2, ou);
+        mean.n = 0;
         // The nResK ResBlock chains only meet in the final sum (Generator_hifigan.cpp:159-173;
         // /root/reference/src/modules/ResBlock1.cpp:55-69 per chain).
         const int nk = M.n_resk;
@@ -1031,9 +1078,12 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
             flops_[3] = f0; bytes_[3] = b0;
             grouped = conv_group_eligible(G);
         }
+#ifdef STS_EXPERIMENTS
         if (grouped && trunk_mode == 2 && conv_math == 0 && nw == 1 && stage_persistent(c, i, bup, l2, reg, ce, outs)) {
             // (the whole stage went out as one persistent launch)
-        } else if (grouped) {
+        } else
+#endif
+        if (grouped) {
             // Layer d of ALL chains goes out as one grouped launch: 2 * nd launches per stage instead of
             // 2 * nd * nResK, nResK times the workgroups per launch (a batch-1 stage otherwise yields only a
             // few hundred), and chains of different kernel size backfill each other inside the grid.
@@ -1199,9 +1249,12 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
                 cur_ = stream;
             }
         }
-        // xs = ((rb_0 + rb_1) + ...) / nResK, written over the (now dead) upsampler output
-        sum_scale(bup, outs, nk, (long)ce, stream);
-        x = bup; S = S2; lx = l2;
+        // xs = ((rb_0 + rb_1) + ...) / nResK (Generator_hifigan.cpp:159-173): formed by the consumer while it stages its input (2 or 3
+        // chains), or -- the fallback -- by a launch that writes it over the (now dead) upsampler output
+        if (nk == 1) x = outs[0];                       // (x / 1 == x)
+        else if (nk <= 3 && !no_sum_fold) { mean.p[0] = outs[0]; mean.p[1] = outs[1]; mean.p[2] = nk > 2 ? outs[2] : nullptr; mean.n = nk; mean.dst = bup; mean.count = (long)ce; x = outs[0]; }
+        else { sum_scale(bup, outs, nk, (long)ce, stream); x = bup; }
+        S = S2; lx = l2;
     }
     in_mfma_region_ = false;
     mark(6);
@@ -1211,10 +1264,12 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
     const long Ntot = Wtot * hop;
     if (M.dec_type == 0) {          // Generator_hifigan.cpp:177-179 + SynthesizerTrn.cpp:389-396
         ConvOpt o; o.in_act = 1; o.slope = 1e-2f; o.epi = EPI_TANH_PCM; o.pcm = bf.pcm; o.aux = wave;
+        with_mean(o);
         conv(M.conv_post, x, lx, nullptr, lx, o);
     } else {                        // Generator_MBB.cpp:174-202, Generator_MS.cpp:198-228, Generator_Istft.cpp:180-197
         const Lvl lsb = lvF(S, 1);
         ConvOpt o; o.in_act = 1; o.slope = 1e-2f; o.reflect = 1;
+        with_mean(o);
         conv(M.conv_post, x, lx, bf.tailA, lsb, o);
         istft_spectrum(bf.tailA, lsb.ld, sbC, bf.tailB, lsb.total, stream);
         const int bands = M.dec_type == 2 ? 1 : 4;
@@ -1264,13 +1319,22 @@ int Engine::run(int B, const int32_t* const* ids, const int32_t* n, const int32_
     const long before = h2_fallbacks;
     int rc = run_once(B, ids, n, sid, ls, ss);
     if ((rc == STS_OK && !ss && *(volatile unsigned*)ovf_host_ != 0u) || rc == kRetrySplitBf16) {
+        if (h2_fallbacks == 0)
+            tts_log(TTS_LOG_WARNING, "summertts_hip: an activation left the fp16 range (|x| > 60000): this call is repeated in the split-bf16 form "
+                                   "(same result, about twice the latency; sts_profile.conv_math_fallbacks counts these; STS_CONV_MATH=bf16x3 avoids them)\n");
         h2_fallbacks++;
         conv_math = 0;
         have_forced = forced;
         rc = run_once(B, ids, n, sid, ls, ss);
     }
     conv_math = 3;
-    if (h2_fallbacks != before) { if (++h2_consecutive >= 2) h2_disabled = true; } else h2_consecutive = 0;
+    if (h2_fallbacks != before) {
+        if (++h2_consecutive >= 2 && !h2_disabled) {
+            h2_disabled = true;
+            tts_log(TTS_LOG_WARNING, "summertts_hip: two calls in a row had to be repeated: this engine now stays in the split-bf16 form "
+                                   "until sts_set_conv_math is called again (sts_profile.conv_math_pinned)\n");
+        }
+    } else h2_consecutive = 0;
     return rc;
 }
 
@@ -1284,7 +1348,9 @@ int Engine::run_once(int B, const int32_t* const* ids, const int32_t* n, const i
     for (double& f : flops_) f = 0;
     for (double& f : bytes_) f = 0;
     mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+#ifdef STS_EXPERIMENTS
     ps_tab_busy_ = false;          // (the previous run ended with a stream synchronisation)
+#endif
 
     RunCtx c;
     c.B = B; c.ids = ids; c.n = n; c.sid = sid; c.ls = ls; c.ss = ss;
@@ -1355,7 +1421,7 @@ int Engine::run_output(RunCtx& c) {
     prof.flops_text_encoder = flops_[0]; prof.flops_duration = flops_[1]; prof.flops_flow = flops_[2]; prof.flops_decoder = flops_[3];
     prof.flops_decoder_mfma = mfma_flops_; prof.decoder_mfma_launches = mfma_launches_; prof.bytes_decoder_min = bytes_[3] + 2.0 * (double)Ntot;
     prof.flops_decoder_mfma_executed = mfma_exec_; prof.flops_decoder_bf16_issued = bf16_exec_;
-    prof.conv_math_fallbacks = h2_fallbacks;
+    prof.conv_math_fallbacks = h2_fallbacks; prof.conv_math_pinned = h2_disabled ? 1 : 0;
     prof.bytes_text_encoder = bytes_[0]; prof.bytes_duration = bytes_[1]; prof.bytes_flow = bytes_[2];
     prof.ms_sync_wait_host = (float)sync_wait_ms_;
     if (profiling) {

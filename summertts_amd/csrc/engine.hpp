@@ -39,6 +39,9 @@ struct ConvOpt {
     int pad_l = -1;            // override the left padding (FFN same_padding)
     int tile = -1;             // force a kernel variant for this conv (as sts_set_conv_mode - 2); -1 = automatic
     int kslices = 1; long kslice_stride = 0;   // cross-workgroup split of K into partial outputs (kernels.hpp ConvArgs::kslices)
+    // the conv's input is the mean ((x + sum1) [+ sum2]) / nsum of tensors of x's geometry (kernels.hpp ConvArgs::nsum); where the kernel
+    // the conv is routed to cannot form it while staging, Engine::conv materialises it into sum_dst (sum_n floats) first
+    const float* sum1 = nullptr; const float* sum2 = nullptr; int nsum = 0; float* sum_dst = nullptr; long sum_n = 0;
 };
 
 // streaming decode: PCM is handed to `cb` chunk by chunk (cb returns non-zero to stop)
@@ -75,9 +78,11 @@ public:
     int h2_consecutive = 0; bool h2_disabled = false;   // two repeats in a row: the engine stays on split-bf16 until sts_set_conv_math
     double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
+#ifdef STS_EXPERIMENTS                 // lab build only (`make exp`): the two persistent-kernel families that lost their A/B
     bool pk_trace = false;             // record the persistent kernel's per-op timeline into taps["pk_trace"] (sts_debug_set)
     int trunk_mode = 0;                // 0 automatic (today: grouped launches), 1 grouped launches, 2 persistent stage kernel where eligible (sts_debug_set)
     int front_mode = 0;                // 0 automatic, 1 one launch per layer, 2 persistent single-XCD kernel wherever eligible (sts_debug_set)
+#endif
     hipStream_t stream = nullptr;
 
 private:
@@ -98,7 +103,9 @@ private:
     int run_flow(RunCtx& c);
     int run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0);
     int run_output(RunCtx& c);
+#ifdef STS_EXPERIMENTS
     bool flow_program();            // builds (once) the op program of the persistent single-launch flow (persist.hip); false: not eligible
+#endif
     void tap(const char* name, const float* d, int channels, long ld, long length);
     void stage_begin(int s);
     void mark(int i);
@@ -110,11 +117,13 @@ private:
     unsigned* ovf_host_ = nullptr; unsigned* ovf_ = nullptr;              // conv_math 3: overflow word (host-mapped) and its device address
     int* hmap_ = nullptr; int* hmap_dev_ = nullptr; size_t hmap_cap_ = 0;   // host-mapped result block of the durations kernel
     unsigned* arrive_ = nullptr; int seq_ = 0;
+#ifdef STS_EXPERIMENTS
     // persistent decoder-stage kernel (conv_bf3_stage): per-XCD private stage buffers, the conv table and its counters
     float* ps_priv_ = nullptr; size_t ps_priv_cap_ = 0; ConvArgs* ps_tab_ = nullptr; ConvArgs* ps_tab_host_ = nullptr; size_t ps_tab_cap_ = 0;
     unsigned* ps_ctr_ = nullptr; size_t ps_ctr_cap_ = 0; bool ps_tab_busy_ = false;
     bool stage_persistent(RunCtx& c, int stage, const float* bup, const Lvl& l2, float* reg, size_t ce, const float** outs);
     PkStep* pk_prog_ = nullptr; int pk_nsteps_ = 0, pk_halo_ = 0, pk_state_ = 0; unsigned* pk_ctr_ = nullptr;   // persistent flow kernel
+#endif
     hipEvent_t ev_[8] = {};
     static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently
     hipStream_t aux_[kAux] = {};

@@ -70,6 +70,10 @@ struct ConvArgs {
     // weights scaled by a power of two (wscale = its inverse, applied to the finished tile); ovf (math 1): raised when a staged
     // input value does not fit fp16
     int math; float wscale; unsigned* ovf;
+    // optional extra input terms (same layout, ld and segments as x): the logical input is ((x + xs1) [+ xs2]) / nsum for nsum = 2 / 3
+    // (0 / 1: plain x) -- the mean over a decoder stage's ResBlock chains (Generator_hifigan.cpp:159-173) formed in the staging code
+    // of the conv that consumes it instead of by a launch of its own.  Taken by conv_bf3 (conv_bf3_takes_sum) and conv_cout1 only.
+    const float* xs1; const float* xs2; int nsum;
 };
 
 // Segmented Winograd F(2,3): a k-tap filter is cut into n3 three-tap segments followed by n2 two-tap segments
@@ -142,6 +146,7 @@ struct AttnArgs {
     int block_min_wgs;              // the 16-queries-per-workgroup matrix-core kernel from this many workgroups on (0: default 96)
 };
 
+#ifdef STS_EXPERIMENTS   // lab build only (`make exp`): persistent-kernel families that lost their A/B against the launch path
 // ---- persistent single-launch flow (persist.hip): the reverse flow of ONE utterance, frame axis cut into 8 windows (one per XCD),
 // every window processed by the workgroups of its XCD with L2-local barriers between the ops
 constexpr int PK_MAX_STEPS = 96;
@@ -184,6 +189,7 @@ struct StageArgs {
 size_t ps_counter_bytes(int nops, int nmem);
 bool conv_bf3_stage_eligible(const ConvArgs& a);
 void conv_bf3_stage(const StageArgs& A, hipStream_t st);
+#endif  // STS_EXPERIMENTS
 
 // ---- launchers (all asynchronous on `st`) ------------------------------------------------------
 // Matrix-core (v_mfma_f32_32x32x2_f32) implicit-GEMM conv.  Returns false when the shape is not
@@ -218,6 +224,9 @@ bool conv_group_eligible(const ConvGroup& G);
 // fp32 conv on the bf16 matrix cores: both operands split exactly into three bf16 terms (x = hi + mid + lo, 24 mantissa
 // bits), the six products of order <= 2^-16 accumulated in fp32 (conv_bf3.hip)
 bool conv_bf3_eligible(const ConvArgs& a);
+// an eligible conv whose automatic tile is instantiated with the summed-input staging (ConvArgs::nsum >= 2)
+bool conv_bf3_takes_sum(const ConvArgs& a);
+bool conv_cout1_takes(const ConvArgs& a);      // conv_generic would route this conv to the single-output-channel FIR kernel
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile = -1);
 // workgroups the automatic tile choice would launch (the caller keeps latency-bound launches on the split-K fp32 kernel)
 long conv_bf3_blocks(const ConvArgs& a);

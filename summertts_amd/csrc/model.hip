@@ -223,6 +223,7 @@ bool pack_bf3(Store& st, DConv& d, bool perm_k = false) {
     return true;
 }
 
+#ifdef STS_EXPERIMENTS
 // copy of an already packed conv in the operand order of the persistent flow kernel (persist.hip): [tap][Cin_pad / 8][Cout_pad][8] --
 // the 8 input channels of a K group contiguous per output row, so that a lane fetches its four k values of a group with ONE
 // 16-byte load (lanes of the upper half-wave take channels 4..7)
@@ -239,6 +240,9 @@ bool pack_k8(Store& st, DConv& d) {
                     p[(((size_t)t * (d.Cin_pad / 8) + cb) * d.Cout_pad + r) * 8 + e] = wh[((size_t)t * d.Cin_pad + cb * 8 + e) * d.Cout_pad + r];
     return true;
 }
+#else
+bool pack_k8(Store&, DConv&) { return true; }     // (only the lab build's persistent flow kernel reads that copy)
+#endif
 
 // extra copy of a square 1x1 conv in the fused column-block kernel's operand order (col_layer.hip)
 bool pack_col(Store& st, const HConv& h, DConv& d, int out_rows = -1) {

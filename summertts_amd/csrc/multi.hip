@@ -10,15 +10,21 @@
 // sts_infer_ids_batch).
 //
 // Two ways of bringing the PCM home (sts_multi_gather_mode):
-//   * RCCL gather (round 3; the xGMI path BASELINE.json's north_star names): when the listed devices are all distinct (and more than
-//     one, or STS_MULTI_RCCL is asked for), the handle owns one RCCL communicator per device (ncclCommInitAll).  After its shard
-//     has run, every worker publishes its sample count with ncclAllGather, ranks > 0 ncclSend their int16 PCM straight out of the
-//     engine's device buffer, rank 0 posts the matching ncclRecvs (one group) into a gather buffer on device 0 laid out by
-//     sts_multi_gather_layout, adds its own shard device-to-device, and ONE device-to-host copy brings the whole batch down.
-//     librccl is dlopen'ed on first use: a process that never asks for the gather never loads it.
-//   * per-device download: each worker downloads its own shard over PCIe (devices that repeat in the list, single device).
-// N > 1 with RCCL has not been measured (no multi-GPU node was available to the builder): the code path is exercised on one GPU
-// with a one-rank communicator (tests/test_parity_gpu.py) and its layout arithmetic on the CPU (tests/test_abi_cpu.py).
+//   * per-device download (the default, STS_MULTI_AUTO / STS_MULTI_DOWNLOAD): each worker downloads its own shard over PCIe.
+//   * RCCL gather (STS_MULTI_RCCL, opt-in; the xGMI path BASELINE.json's north_star names): the handle owns one RCCL communicator
+//     per device (ncclCommInitAll; distinct devices).  After its shard has run, every worker publishes its sample count with
+//     ncclAllGather; rank 0 sizes the gather buffer and every rank learns through a second one-word ncclAllGather whether
+//     rank 0 can receive (a local failure on ANY rank before the transfer therefore cancels the transfer on ALL ranks instead of
+//     leaving peers blocked in ncclSend); then ranks > 0 ncclSend their int16 PCM straight out of the engine's device buffer, rank 0
+//     posts the matching ncclRecvs (one group) into the gather buffer on device 0 laid out by sts_multi_gather_layout, adds its own
+//     shard device-to-device, and ONE device-to-host copy brings the whole batch down.  Every wait on a collective is bounded
+//     (kCollectiveTimeoutMs): on a timeout or an RCCL error all communicators are aborted (ncclCommAbort), the call fails and
+//     the handle continues with per-device downloads.  librccl is dlopen'ed on first use: a process that never asks for the gather
+//     never loads it.
+// The RCCL path has been exercised with one rank on the real library and with THREE ranks against tests/fake_rccl (a host-side
+// stand-in for the seven entry points used here, selected through sts_multi_set_rccl_library -- a test hook): pairing, zero-count
+// ranks, a failing shard, buffer regrowth.  Hardware N > 1 remains unmeasured (no multi-GPU node was available to the builder) --
+// which is why the automatic mode does not select it.
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +32,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -51,16 +58,20 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional
     std::string err;
+    std::string override_path; bool allow_repeated = false;   // sts_multi_set_rccl_library (test hook)
     bool load() {
         if (h) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!override_path.empty()) h = dlopen(override_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        else for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
         if (!h) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
         auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         AllGather = (decltype(AllGather))sym("ncclAllGather"); Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");
         return CommInitAll && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd && GetErrorString;
     }
 };
@@ -87,56 +98,104 @@ struct sts_multi {
     // RCCL gather state (gather_mode == 1)
     int gather_mode = 0;
     std::vector<ncclComm_t> comms;
-    std::vector<long long*> d_counts;       // per device: [1 own count | ndev gathered counts]
+    std::vector<long long*> d_counts;       // per device: [1 own word | ndev gathered words]
     int16_t* d_gather = nullptr; size_t gather_cap = 0;      // on engines[0]'s device
     int16_t* h_gather = nullptr; size_t h_gather_cap = 0;    // pinned
     std::vector<int64_t> counts, offsets; int64_t gather_total = 0;
+    bool rccl_broken = false;               // a collective failed or timed out: communicators aborted, downloads from the next call on
+    static constexpr int kCollectiveTimeoutMs = 60000;
 
-    // after the shard has run: counts -> all ranks, PCM of ranks > 0 -> rank 0 over xGMI, rank 0 downloads everything at once
+    // all communicators of the handle go down together: a peer blocked in a collective returns with an error instead of hanging
+    void abort_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rccl_broken) return;
+        rccl_broken = true;
+        Rccl& R = rccl();
+        if (R.CommAbort) for (auto& c : comms) if (c) { (void)R.CommAbort(c); c = nullptr; }
+    }
+    bool broken() { std::lock_guard<std::mutex> lk(mu); return rccl_broken; }
+    // bounded wait for everything queued on a rank's stream (collectives included); false also when a PEER brought the communicators down
+    bool wait_stream(Shard& sh, hipStream_t st, const char* what) {
+        const bool done = wait_stream_raw(sh, st, what);
+        if (done && broken()) { if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": the communicators were aborted by a peer's failure"; } return false; }
+        return done;
+    }
+    bool wait_stream_raw(Shard& sh, hipStream_t st, const char* what) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spin = 0;; spin++) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return true;
+            if (q != hipErrorNotReady) { if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + hipGetErrorString(q); } abort_all(); return false; }
+            if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
+            if ((spin & 0xff) == 0xff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(kCollectiveTimeoutMs)) {
+                if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": timed out waiting for the peers (communicators aborted)"; }
+                abort_all();
+                (void)hipStreamSynchronize(st);     // the aborted collective's kernel leaves the stream
+                return false;
+            }
+        }
+    }
+
+    // after the shard has run: counts -> all ranks, "can receive" of rank 0 -> all ranks, PCM of ranks > 0 -> rank 0 over xGMI,
+    // rank 0 downloads everything at once.  No rank ever blocks on a transfer that another rank will not post.
     void rccl_gather(int k) {
         Shard& sh = shards[k];
         Engine& eng = *engines[k];
         Rccl& R = rccl();
         const int nd = (int)engines.size();
         const long long mine = sh.rc == STS_OK && !sh.utt.empty() ? (long long)eng.total_samples : 0;    // a failed shard still takes part
-        auto ck = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess && sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + R.GetErrorString(r); } return r == ncclSuccess; };
+        auto ck = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess) { if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + R.GetErrorString(r); } abort_all(); } return r == ncclSuccess; };
         auto hk = [&](hipError_t e, const char* what) { if (e != hipSuccess && sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + hipGetErrorString(e); } return e == hipSuccess; };
-        long long host_counts[65];
-        hk(hipMemcpyAsync(d_counts[k], &mine, sizeof(long long), hipMemcpyHostToDevice, eng.stream), "count upload");
-        ck(R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, comms[k], eng.stream), "ncclAllGather");
-        hk(hipMemcpyAsync(host_counts, d_counts[k] + 1, sizeof(long long) * nd, hipMemcpyDeviceToHost, eng.stream), "count download");
-        hk(hipStreamSynchronize(eng.stream), "count sync");
+        long long host_words[65];
+        // ---- round 1: sample counts
+        bool ok = hk(hipMemcpyAsync(d_counts[k], &mine, sizeof(long long), hipMemcpyHostToDevice, eng.stream), "count upload");
+        ok = ok && ck(R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, comms[k], eng.stream), "ncclAllGather (counts)");
+        ok = ok && hk(hipMemcpyAsync(host_words, d_counts[k] + 1, sizeof(long long) * nd, hipMemcpyDeviceToHost, eng.stream), "count download");
+        ok = ok && wait_stream(sh, eng.stream, "count exchange");
+        if (!ok) { abort_all(); return; }                    // (a local HIP failure: nobody waits for this rank once the communicators are down)
+        // ---- rank 0 sizes its buffers; round 2: every rank's "ready" word (rank 0: the buffers exist; others: nothing failed locally)
+        long long ready = 1;
+        if (k == 0) {
+            counts.assign(host_words, host_words + nd);
+            offsets.resize(nd);
+            gather_total = sts_multi_gather_layout(counts.data(), nd, offsets.data());
+            const size_t need = (size_t)std::max<int64_t>(gather_total, 1);
+            if (need > gather_cap) {
+                if (d_gather) (void)hipFree(d_gather);
+                d_gather = nullptr; gather_cap = 0;
+                if (hk(hipMalloc((void**)&d_gather, (need + need / 4) * 2), "gather buffer")) gather_cap = need + need / 4;
+            }
+            if (need > h_gather_cap) {
+                if (h_gather) (void)hipHostFree(h_gather);
+                h_gather = nullptr; h_gather_cap = 0;
+                if (hk(hipHostMalloc((void**)&h_gather, (need + need / 4) * 2, hipHostMallocDefault), "pinned gather buffer")) h_gather_cap = need + need / 4;
+            }
+            ready = d_gather && h_gather && gather_cap >= need && h_gather_cap >= need ? 1 : 0;
+        }
+        ok = hk(hipMemcpyAsync(d_counts[k], &ready, sizeof(long long), hipMemcpyHostToDevice, eng.stream), "ready upload");
+        ok = ok && ck(R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, comms[k], eng.stream), "ncclAllGather (ready)");
+        ok = ok && hk(hipMemcpyAsync(host_words, d_counts[k] + 1, sizeof(long long) * nd, hipMemcpyDeviceToHost, eng.stream), "ready download");
+        ok = ok && wait_stream(sh, eng.stream, "ready exchange");
+        if (!ok) { abort_all(); return; }
+        for (int p = 0; p < nd; p++)
+            if (host_words[p] != 1) {                        // somebody cannot take part: no rank posts a transfer, the call fails, nothing hangs
+                if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = "RCCL gather cancelled: rank " + std::to_string(p) + " could not allocate its buffers"; }
+                return;
+            }
+        // ---- the transfer
         if (k > 0) {
-            if (mine > 0) ck(R.Send(eng.d_pcm, (size_t)mine, ncclHalf, 0, comms[k], eng.stream), "ncclSend");
-            hk(hipStreamSynchronize(eng.stream), "send sync");       // the engine's PCM buffer is free again
+            if (mine > 0 && ck(R.Send(eng.d_pcm, (size_t)mine, ncclHalf, 0, comms[k], eng.stream), "ncclSend"))
+                (void)wait_stream(sh, eng.stream, "ncclSend");      // the engine's PCM buffer is free again
             return;
         }
-        // rank 0: layout, receive, own shard, one download
-        counts.assign(host_counts, host_counts + nd);
-        offsets.resize(nd);
-        gather_total = sts_multi_gather_layout(counts.data(), nd, offsets.data());
-        const size_t need = (size_t)std::max<int64_t>(gather_total, 1);
-        if (need > gather_cap) {
-            if (d_gather) (void)hipFree(d_gather);
-            d_gather = nullptr; gather_cap = 0;
-            if (hk(hipMalloc((void**)&d_gather, (need + need / 4) * 2), "gather buffer")) gather_cap = need + need / 4;
-        }
-        if (need > h_gather_cap) {
-            if (h_gather) (void)hipHostFree(h_gather);
-            h_gather = nullptr; h_gather_cap = 0;
-            if (hk(hipHostMalloc((void**)&h_gather, (need + need / 4) * 2, hipHostMallocDefault), "pinned gather buffer")) h_gather_cap = need + need / 4;
-        }
-        // the receives are posted even after a local failure (into a scratch-sized buffer they would not fit: then fail the job but
-        // keep the peers from hanging is impossible -- so allocation failure above is fatal for the process' job, reported)
-        if (d_gather && gather_cap >= need) {
-            ck(R.GroupStart(), "ncclGroupStart");
-            for (int p = 1; p < nd; p++)
-                if (counts[p] > 0) ck(R.Recv(d_gather + offsets[p], (size_t)counts[p], ncclHalf, p, comms[0], eng.stream), "ncclRecv");
-            ck(R.GroupEnd(), "ncclGroupEnd");
-            if (mine > 0) hk(hipMemcpyAsync(d_gather + offsets[0], eng.d_pcm, (size_t)mine * 2, hipMemcpyDeviceToDevice, eng.stream), "own shard");
-            if (h_gather) hk(hipMemcpyAsync(h_gather, d_gather, (size_t)gather_total * 2, hipMemcpyDeviceToHost, eng.stream), "gather download");
-        }
-        hk(hipStreamSynchronize(eng.stream), "gather sync");
+        bool posted = ck(R.GroupStart(), "ncclGroupStart");
+        for (int p = 1; p < nd && posted; p++)
+            if (counts[p] > 0) posted = ck(R.Recv(d_gather + offsets[p], (size_t)counts[p], ncclHalf, p, comms[0], eng.stream), "ncclRecv");
+        posted = ck(R.GroupEnd(), "ncclGroupEnd") && posted;
+        if (!posted) return;
+        if (mine > 0) hk(hipMemcpyAsync(d_gather + offsets[0], eng.d_pcm, (size_t)mine * 2, hipMemcpyDeviceToDevice, eng.stream), "own shard");
+        if (gather_total > 0) hk(hipMemcpyAsync(h_gather, d_gather, (size_t)gather_total * 2, hipMemcpyDeviceToHost, eng.stream), "gather download");
+        (void)wait_stream(sh, eng.stream, "gather");
     }
 
     void worker(int k) {
@@ -168,7 +227,11 @@ struct sts_multi {
                     sh.err = eng.error();
                 }
             }
-            if (gather_mode == 1) rccl_gather(k);       // every rank takes part, also with an empty or failed shard
+            if (gather_mode == 1) {       // every rank takes part, also with an empty or failed shard
+                bool alive; { std::lock_guard<std::mutex> lk(mu); alive = !rccl_broken; }
+                if (alive) rccl_gather(k);
+                else if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = "RCCL communicators were aborted by an earlier failure"; }
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 pending--;
@@ -216,6 +279,18 @@ int64_t sts_multi_gather_layout(const int64_t* counts, int32_t n_ranks, int64_t*
 
 int sts_multi_gather_mode(const sts_multi* m) { return m ? m->gather_mode : 0; }
 
+// Test hook: the shared library that provides the nccl* entry points (default: librccl.so.1) and whether STS_MULTI_RCCL may list a
+// device more than once (real RCCL refuses that; tests/fake_rccl emulates N ranks on ONE GPU).  Takes effect for handles created
+// afterwards, and only before the first successful load in the process.
+int sts_multi_set_rccl_library(const char* path, int allow_repeated_devices) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    Rccl& R = rccl();
+    if (R.h) return multi_err(STS_ESTATE, "an RCCL library is already loaded in this process");
+    R.override_path = path ? path : "";
+    R.allow_repeated = allow_repeated_devices != 0;
+    return STS_OK;
+}
+
 int sts_multi_create(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, sts_multi** out) {
     return sts_multi_create_ex(blob, blob_bytes, devices, n_devices, STS_MULTI_AUTO, out);
 }
@@ -227,8 +302,9 @@ int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* de
     if (flags != STS_MULTI_AUTO && flags != STS_MULTI_RCCL && flags != STS_MULTI_DOWNLOAD) return multi_err(STS_EINVAL, "unknown flags");
     bool distinct = true;
     for (int a = 0; a < n_devices; a++) for (int b = a + 1; b < n_devices; b++) if (devices[a] == devices[b]) distinct = false;
-    if (flags == STS_MULTI_RCCL && !distinct) return multi_err(STS_EINVAL, "the RCCL gather needs distinct devices (one communicator rank per GPU)");
-    const bool want_rccl = flags == STS_MULTI_RCCL || (flags == STS_MULTI_AUTO && distinct && n_devices >= 2);
+    if (flags == STS_MULTI_RCCL && !distinct && !rccl().allow_repeated) return multi_err(STS_EINVAL, "the RCCL gather needs distinct devices (one communicator rank per GPU)");
+    // the automatic mode = per-device downloads: the RCCL gather has never run on N > 1 real devices, so it is opt-in
+    const bool want_rccl = flags == STS_MULTI_RCCL;
     sts_multi* m = new (std::nothrow) sts_multi();
     if (!m) return multi_err(STS_EDEVICE, "out of host memory");
     for (int k = 0; k < n_devices; k++) {
@@ -272,7 +348,7 @@ void sts_multi_destroy(sts_multi* m) {
     { std::lock_guard<std::mutex> lk(m->mu); m->stop = true; }
     m->cv_go.notify_all();
     for (auto& t : m->workers) t.join();
-    for (size_t k = 0; k < m->comms.size(); k++) if (m->comms[k]) (void)rccl().CommDestroy(m->comms[k]);
+    for (size_t k = 0; k < m->comms.size(); k++) if (m->comms[k]) (void)rccl().CommDestroy(m->comms[k]);      // (aborted communicators were nulled)
     for (size_t k = 0; k < m->d_counts.size(); k++) if (m->d_counts[k]) { (void)hipSetDevice(m->engines[k]->device); (void)hipFree(m->d_counts[k]); }
     if (m->d_gather) { (void)hipSetDevice(m->engines[0]->device); (void)hipFree(m->d_gather); }
     if (m->h_gather) (void)hipHostFree(m->h_gather);
@@ -301,6 +377,7 @@ int sts_multi_infer_ids_batch(sts_multi* m, int32_t B, const int32_t* const* ids
     for (int b = 0; b < B; b++) { pcm_out[b] = nullptr; n_out[b] = 0; }      // every output is defined before the first early return
     for (int b = 0; b < B; b++) if (n[b] <= 0 || !ids[b]) return multi_err(STS_EINVAL, "utterance with no phonemes");
     const int ndev = (int)m->engines.size();
+    const bool was_gather = m->gather_mode == 1;
     {
         std::unique_lock<std::mutex> lk(m->mu);
         shard_by_phonemes(B, n, ndev, m->shards);
@@ -311,9 +388,17 @@ int sts_multi_infer_ids_batch(sts_multi* m, int32_t B, const int32_t* const* ids
         m->cv_done.wait(lk, [&] { return m->pending == 0; });
     }
     int rc = STS_OK;
+    const bool gathered = was_gather && !m->rccl_broken;
+    if (was_gather && m->rccl_broken) {          // this call fails; the next ones bring the PCM home by per-device downloads
+        m->gather_mode = 0;
+        for (auto& e : m->engines) e->host_pcm = true;
+        bool any = false;
+        for (auto& sh : m->shards) any = any || sh.rc != STS_OK;
+        if (!any) rc = multi_err(STS_EDEVICE, "RCCL gather failed (communicators aborted)");
+    }
     for (int k = 0; k < ndev && rc == STS_OK; k++)
         if (m->shards[k].rc != STS_OK) rc = multi_err(m->shards[k].rc, "device slot " + std::to_string(k) + ": " + m->shards[k].err);
-    if (rc == STS_OK && m->gather_mode == 1) {
+    if (rc == STS_OK && gathered) {
         // the counts every rank published must be the ones the engines reported on the host
         for (int k = 0; k < ndev && rc == STS_OK; k++) {
             int64_t want = 0;
@@ -326,7 +411,7 @@ int sts_multi_infer_ids_batch(sts_multi* m, int32_t B, const int32_t* const* ids
     for (int k = 0; k < ndev && rc == STS_OK; k++) {
         const Shard& sh = m->shards[k];
         size_t off = 0;
-        const int16_t* src = m->gather_mode == 1 ? m->h_gather + m->offsets[k] : sh.pcm.data();
+        const int16_t* src = gathered ? m->h_gather + m->offsets[k] : sh.pcm.data();
         for (size_t i = 0; i < sh.utt.size() && rc == STS_OK; i++) {
             const int u = sh.utt[i];
             const int32_t ns = sh.n_samples[i];

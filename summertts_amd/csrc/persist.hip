@@ -28,6 +28,9 @@
 //   * a wave waits for its stores (s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the completion signal;
 //   * counters are relaxed agent-scope atomics (executed in L2); no agent-scope fence anywhere (an acquire fence costs
 //     more than the barrier itself: 10.9 vs 4.9 us per round in the micro-benchmark).
+// Lab build only (-DSTS_EXPERIMENTS, `make exp`): measured slower than the launch-per-layer path (0.50 vs 0.44 ms), so the
+// shipped library does not carry it -- no pk_* symbol, no extra weight copy, no sts_debug_set key.
+#ifdef STS_EXPERIMENTS
 #include "kernels.hpp"
 #include "devmath.hpp"
 #include "conv_common.hpp"
@@ -380,3 +383,4 @@ void pk_flow(const PkFlowArgs& A, hipStream_t st) {
 }
 
 }  // namespace sts
+#endif  // STS_EXPERIMENTS

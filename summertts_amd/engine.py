@@ -39,7 +39,7 @@ class Profile(C.Structure):
                 ("samples", C.c_int64), ("phonemes", C.c_int64), ("flops_decoder_mfma_executed", C.c_double),
                 ("bytes_text_encoder", C.c_double), ("bytes_duration", C.c_double), ("bytes_flow", C.c_double),
                 ("ms_sync_wait_host", C.c_float), ("flops_decoder_bf16_issued", C.c_double),
-                ("conv_math_fallbacks", C.c_int64)]
+                ("conv_math_fallbacks", C.c_int64), ("conv_math_pinned", C.c_int32), ("reserved0", C.c_int32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -76,6 +76,7 @@ def load_library() -> C.CDLL:
     lib.sts_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sts_set_host_pcm.argtypes = [C.c_void_p, C.c_int]
     lib.sts_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
+    lib.sts_get_profile_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.sts_get_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64)]
     lib.sts_get_durations.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -96,8 +97,13 @@ EXPORTED_SYMBOLS = [
     "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack", "sts_debug_set", "sts_multi_create_ex", "sts_multi_gather_mode", "sts_multi_gather_layout",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
     "sts_multi_create", "sts_multi_destroy", "sts_multi_device_count", "sts_multi_speaker_num", "sts_multi_infer_ids_batch",
-    "sts_multi_shard_of", "sts_multi_last_error",
+    "sts_multi_shard_of", "sts_multi_last_error", "sts_multi_set_rccl_library", "sts_get_profile_ex", "sts_abi_version", "sts_build_flags",
 ]
+
+
+def lab_build() -> bool:
+    """True when the loaded library was built with -DSTS_EXPERIMENTS (`make -C summertts_amd/csrc exp`)."""
+    return bool(load_library().sts_build_flags() & 1)
 
 
 class StsError(RuntimeError):
@@ -222,7 +228,7 @@ class Synthesizer:
 
     def profile(self) -> dict:
         p = Profile()
-        _check(self.lib, self.lib.sts_get_profile(self.h, C.byref(p)))
+        _check(self.lib, self.lib.sts_get_profile_ex(self.h, C.byref(p), C.sizeof(p)))
         return p.as_dict()
 
     def tap(self, name: str) -> np.ndarray:
@@ -355,8 +361,8 @@ class MultiDevice:
     MODES = {"auto": 0, "rccl": 1, "download": 2}
 
     def __init__(self, blob: np.ndarray, devices: Sequence[int], gather: str = "auto"):
-        """gather: 'auto' (RCCL gather to devices[0] when the devices are distinct and more than one) | 'rccl' (force it, also for
-        one device) | 'download' (every device downloads its own shard)."""
+        """gather: 'auto' / 'download' (every device downloads its own shard) | 'rccl' (opt-in: RCCL gather to devices[0];
+        distinct devices, one is allowed)."""
         self.lib = load_library()
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         dev = np.ascontiguousarray(devices, dtype=np.int32)
@@ -377,6 +383,17 @@ class MultiDevice:
 
     def gather_mode(self) -> str:
         return "rccl" if int(self.lib.sts_multi_gather_mode(self.h)) == 1 else "download"
+
+    @staticmethod
+    def set_rccl_library(path: Optional[str], allow_repeated_devices: bool = False):
+        """Test hook (sts_multi_set_rccl_library): which shared library provides the nccl* entry points; only before the first
+        'rccl' handle of the process."""
+        lib = load_library()
+        lib.sts_multi_set_rccl_library.argtypes = [C.c_char_p, C.c_int]
+        lib.sts_multi_last_error.restype = C.c_char_p
+        rc = lib.sts_multi_set_rccl_library(path.encode() if path else None, 1 if allow_repeated_devices else 0)
+        if rc != 0:
+            raise StsError(f"sts_multi_set_rccl_library: {rc}: {lib.sts_multi_last_error().decode()}")
 
     def device_count(self) -> int:
         return int(self.lib.sts_multi_device_count(self.h))
