@@ -270,10 +270,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", type=int, default=0)
     ap.add_argument("--conv-math", default=_env_conv_math(), choices=["bf16x3", "f32", "f16x2"],
-                    help="arithmetic of the decoder trunk convs: bf16x3 = fp32 operands split exactly into three bf16 terms, six bf16 "
-                         "MFMA products per fp32 product, fp32 accumulation (default, same parity tolerances); f32 = the exact-fp32 MFMA; "
-                         "f16x2 = two fp16 terms, three fp16 MFMA products per fp32 product (same parity tolerances, half the matrix time)")
+                    help="arithmetic of the decoder trunk convs: f16x2 (default) = fp32 operands as two fp16 terms, three fp16 MFMA products per "
+                         "fp32 product, fp32 accumulation; bf16x3 = fp32 operands split exactly into three bf16 terms, six bf16 MFMA products; "
+                         "f32 = the exact-fp32 MFMA.  One set of parity tolerances for all three; the line carries a timed leg of each")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed leg on the exact-fp32 MFMA path")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
+                    help="lab use: sts_debug_set on the timed engine, e.g. tile_claim=0 (A/B of a dispatch choice in one process / on one box)")
     ap.add_argument("--pipeline-engines", type=int, default=2,
                     help="extra (not the headline): throughput with this many engines fed by concurrent host threads, "
                          "so one utterance's latency-bound text side overlaps another's decoder; 0 disables")
@@ -323,6 +325,9 @@ def main():
     syn.set_conv_mode(args.conv_mode)
     if hasattr(syn, "set_conv_math"):
         syn.set_conv_math(args.conv_math)
+    for kv in args.debug_set:
+        k, v = kv.split("=")
+        syn.debug_set(k, int(v))
     if dist is not None and args.backend == "nccl" and hasattr(syn, "set_host_pcm"):
         syn.set_host_pcm(False)          # the PCM goes device-to-device into the RCCL gather
 

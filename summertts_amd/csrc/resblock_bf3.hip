@@ -19,11 +19,18 @@ int tile_trace_bind_resblock(long long* buf, unsigned capacity_records) { return
 // The intermediate is parked in the k order the accumulator layout gives for free (a lane holds rows 4 h + {0..3} and
 // 8 + 4 h + {0..3} of every 16-row block = one 16-byte unit per plane); conv2's weights are packed to match (perm_k).
 // ------------------------------------------------------------------------------------------------
-template <int MW, int WM, int NW, int WN, int MATH = 0>
-// STS_RB_WAVES (lab switch): waves per SIMD the register budget of the one-row-tile-per-wave forms (MW == 1) is sized for
+// Waves per SIMD the register budget of the one-row-tile-per-wave forms (MW == 1: the 64- and 32-channel stages) is sized for.  Round 4:
+// these forms needed 170 registers under a budget of 256 -- two more than the 168 that allow THREE waves per SIMD.  Capped at 168 (no
+// spill) three workgroups share a CU instead of two and hide each other's staging / park / epilogue phases: -62 us per one-utterance step,
+// -2.2 % at batch 32 (profiles/r04_ab_log.md).  Four (128 registers) spills 170-180 bytes per lane.
+// Also measured in round 4 and NOT kept: a resident set of workgroups that claims tiles through per-XCD L2 counters instead of one
+// workgroup per tile (the launch runs as 4-5 rounds whose boundaries idle half the chip, slot fill 0.75-0.82 in the tile trace) --
+// +6 % SLOWER at one utterance, +10 % at batch 32: the tile body inlined into a loop spills 150 bytes per lane at 168 registers and
+// the claim adds a barrier pair per tile, which costs more than the round boundaries it removes.
 #ifndef STS_RB_WAVES
-#define STS_RB_WAVES 2
+#define STS_RB_WAVES 3
 #endif
+template <int MW, int WM, int NW, int WN, int MATH = 0>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW == 1 ? STS_RB_WAVES : 2, MW == 1 ? STS_RB_WAVES : 2))) void resblock_bf3_kernel(ResLayerGroup G, int nx, int wst, int interleave) {
     constexpr int C = 32 * MW * WM, NCH = C / 16, NRT = C / 32, NWAVE = WM * WN, P1 = 32 * NW * WN;
     constexpr int NPB = MATH ? 2 : 3;            // planes of a staged / parked activation
