@@ -7,12 +7,13 @@ namespace sts {
 #ifdef STS_TILE_TRACE
 int tile_trace_bind_group(long long* buf, unsigned capacity_records);       // conv_bf3_group.hip
 int tile_trace_bind_resblock(long long* buf, unsigned capacity_records);    // resblock_bf3.hip
+int tile_trace_bind_flow(long long* buf, unsigned capacity_records);        // wn_flow.hip
 static long long* g_tt_host_buf = nullptr;
 extern "C" int sts_debug_tile_trace(long long* buf, unsigned capacity_records) {
     // buf: device memory of (16 + 12 * capacity_records) 64-bit words (null: tracing off)
     g_tt_host_buf = buf;
     if (buf && hipMemset(buf, 0, 16 * sizeof(long long)) != hipSuccess) return -1;
-    if (tile_trace_bind(buf, capacity_records) || tile_trace_bind_group(buf, capacity_records) || tile_trace_bind_resblock(buf, capacity_records)) return -1;
+    if (tile_trace_bind(buf, capacity_records) || tile_trace_bind_group(buf, capacity_records) || tile_trace_bind_resblock(buf, capacity_records) || tile_trace_bind_flow(buf, capacity_records)) return -1;
     return 0;
 }
 extern "C" int sts_debug_tile_trace_count() {
@@ -147,7 +148,12 @@ bool conv_bf3_takes_sum(const ConvArgs& a) {
     if (!conv_bf3_eligible(a) || a.nsum < 2 || a.nsum > 3 || !a.xs1 || (a.nsum == 3 && !a.xs2)) return false;
     const int nphase = a.transposed ? a.out_stride : 1;
     const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
-    return tile == 0 || tile == 20 || tile == 22 || tile == 23;
+    // every workgroup that stages a window forms the mean itself (3 reads + a division per staged value), so the fold only pays where a
+    // window is staged once or twice: the phase-merged tiles whose row space (phases x Cout) fits one or two workgroups.  Measured
+    // (profiles/r04_ab_log.md): stage-2 upsampler, 8 phases x 128 rows on 128-row tiles: 61 us folded vs 48 + 6; stages 3 / 4: 34 vs 25.5 + 14
+    if (tile == 22) return (long)nphase * a.Cout_pad <= 2 * 128;
+    if (tile == 23) return (long)nphase * a.Cout_pad <= 2 * 64;
+    return false;
 }
 
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {

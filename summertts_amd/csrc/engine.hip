@@ -404,6 +404,7 @@ struct BufT {
 };
 struct BufF {
     float *z, *h, *acts, *out, *x0, *regA, *regB, *tailA, *tailB, *tailC, *wave, *fliptmp, *pk; long long* pk_trace;
+    float *ff_h[2], *ff_part[2], *ff_macc[2], *ff_alt;        // one-launch-per-layer flow (wn_flow.hip): channel-minor h / partial sums / -m slices, alternate home of a z half
     int16_t* pcm;
 };
 
@@ -423,6 +424,7 @@ struct Engine::RunCtx {
     long Ftot = 0; int maxF = 0, hop = 0;
     int halo = 0; long Wcap = 0; int upS = 1; long Lsb = 0; int sbC = 0;
     bool use_pk = false; int pk_fs = 0, pk_wld = 0, pk_rows = 0;
+    bool use_ff = false; int ffG = 0;
 };
 #define RUN_ALIASES(c)                                                                                                              \
     [[maybe_unused]] Model& M = model;                                                                                              \
@@ -439,6 +441,7 @@ struct Engine::RunCtx {
     [[maybe_unused]] const long Ftot = (c).Ftot; [[maybe_unused]] const int maxF = (c).maxF, hop = (c).hop;                         \
     [[maybe_unused]] const int halo = (c).halo; [[maybe_unused]] const long Wcap = (c).Wcap, Lsb = (c).Lsb;                         \
     [[maybe_unused]] const int upS = (c).upS, sbC = (c).sbC;                                                                        \
+    [[maybe_unused]] const bool use_ff = (c).use_ff; [[maybe_unused]] const int ffG = (c).ffG;                                      \
     [[maybe_unused]] const bool use_pk = (c).use_pk; [[maybe_unused]] const int pk_fs = (c).pk_fs, pk_wld = (c).pk_wld, pk_rows = (c).pk_rows;
 
 // ---- stage 0: batch geometry at the phoneme level, phoneme-level workspace, the one host-to-device copy of a run
@@ -774,9 +777,27 @@ int Engine::run_frame_workspace(RunCtx& c) {
     const bool use_pk = c.use_pk = false;       // (the shipped library carries no persistent flow kernel)
     const int pk_fs = 0, pk_wld = 0, pk_rows = 0;
 #endif
+    // the reverse flow as one launch per WaveNet layer (wn_flow.hip): every coupling must carry the fused operands, with one geometry
+    bool use_ff = flow_fused && !use_pk && conv_mode == 0 && conv_math == 3 && !M.cp.empty() && wnH > 0;
+    for (size_t i = 0; i < M.cp.size() && use_ff; i++)
+        use_ff = M.cp[i].ff.ok && M.cp[i].wn.H == wnH && M.cp[i].wn.n == c.wnL && M.cp[i].ff.G == M.cp[0].ff.G && M.cp[i].wn.in[0].k == M.cp[0].wn.in[0].k;
+    if (use_ff) {
+        // one round of workgroups at most: a workgroup re-pulls its group's ~290 KB of weights for 32 frames, which pays while the launch
+        // is latency-bound (668 frames: 0.31 vs 0.45 ms) and loses by 2.6x once it is not (batch 32: 7.3 vs 2.8 ms; profiles/r04_ab_log.md)
+        long tiles = 0;
+        for (int b = 0; b < B; b++) tiles += (p_lenF[b] + 31) / 32;
+        use_ff = tiles * M.cp[0].ff.G <= 256;
+    }
+    c.use_ff = use_ff; c.ffG = use_ff ? M.cp[0].ff.G : 0;
     BufF& bf = c.bf;
     auto layoutF = [&](Arena& A) {
         A.used = 0;
+        for (int q = 0; q < 2; q++) {
+            bf.ff_h[q] = A.get<float>(use_ff ? (size_t)wnH * Ftot : 1);
+            bf.ff_part[q] = A.get<float>(use_ff ? (size_t)c.ffG * wnH * Ftot : 1);
+            bf.ff_macc[q] = A.get<float>(use_ff ? (size_t)c.ffG * (C / 2) * Ftot : 1);
+        }
+        bf.ff_alt = A.get<float>(use_ff ? (size_t)C * Ftot : 1);
 #ifdef STS_EXPERIMENTS
         bf.pk = A.get<float>(use_pk ? (size_t)8 * 4 * pk_rows * pk_wld : 1);
         bf.pk_trace = A.get<long long>(use_pk && pk_trace ? (size_t)256 * PK_MAX_STEPS * 8 : 1);
@@ -810,6 +831,75 @@ int Engine::run_flow(RunCtx& c) {
     // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
     stage_begin(2);
     const int half = C / 2;
+    if (use_ff) {
+        expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream);
+        tap("z_p", bf.z, C, Ftot, Ftot);
+        const int G = ffG;
+        const size_t hF = (size_t)half * Ftot;
+        // where the newest version of each half of z lives: z itself, or the alternate buffer (a first layer that applies the previous
+        // coupling's pending -m to its x0 half must not write over what its neighbours still read)
+        const float* cur[2] = {bf.z, bf.z + hF};
+        float* const home[2] = {bf.z, bf.z + hF};
+        float* const alt[2] = {bf.ff_alt, bf.ff_alt + hF};
+        int pend_set = -1, pend_half = -1;
+        auto finish_half = [&](int hh, int set) {       // home[hh] = cur[hh] (+ the pending slices of `set`)
+            FlowFinishArgs Fa;
+            memset(&Fa, 0, sizeof(Fa));
+            Fa.seg = lv1.seg; Fa.B = B; Fa.max_len = maxF; Fa.half = half;
+            Fa.src = cur[hh]; Fa.src_ld = Ftot; Fa.dst = home[hh]; Fa.dst_ld = Ftot;
+            Fa.macc = set >= 0 ? bf.ff_macc[set] : nullptr; Fa.n = set >= 0 ? G : 0; Fa.macc_stride = (long)hF;
+            flow_finish(Fa, stream);
+            cur[hh] = home[hh];
+        };
+        int cs = 0;
+        for (int i = M.n_flows - 1; i >= 0; i--, cs ^= 1) {
+            const DCoupling& cp = M.cp[i];
+            const DWn& w = cp.wn;
+            const DFlowFused& ff = cp.ff;
+            const int x0h = cp.flipped ? 1 : 0, x1h = 1 - x0h;
+            if (pend_set >= 0 && pend_half != x0h) { finish_half(pend_half, pend_set); pend_set = -1; }     // (couplings that do not alternate halves)
+            if (w.has_cond) conv(w.cond, bt.g, lvB, bt.cond_wn, lvB, ConvOpt());
+            (void)conv_args(cp.pre, nullptr, lv1, nullptr, lv1, ConvOpt(), nullptr);          // the stage's FLOP / byte account, as for the per-conv launches
+            for (int l = 0; l < w.n; l++) {
+                ConvOpt og; og.epi = EPI_GATE;
+                (void)conv_args(w.in[l], nullptr, lv1, nullptr, lv1, og, nullptr);
+                ConvOpt orr; orr.epi = EPI_RESSKIP;
+                (void)conv_args(w.rs[l], nullptr, lv1, nullptr, lv1, orr, nullptr);
+                FlowLayerArgs A;
+                memset(&A, 0, sizeof(A));
+                A.seg = lv1.seg; A.B = B; A.max_len = maxF; A.tot = Ftot;
+                A.H = w.H; A.half = half; A.G = G; A.Cg = ff.Cg; A.k = w.in[l].k; A.halo = (w.in[l].k - 1) / 2;
+                A.layer = l;
+                if (l == 0) {
+                    A.x0 = cur[x0h]; A.x0_ld = Ftot;
+                    if (pend_set >= 0) {
+                        A.pend = bf.ff_macc[pend_set]; A.pend_n = G; A.pend_stride = (long)hF;
+                        A.x0_out = cur[x0h] == home[x0h] ? alt[x0h] : home[x0h]; A.x0_out_ld = Ftot;
+                    }
+                    A.w_pre = cp.pre.wh2; A.b_pre = cp.pre.bias; A.s_pre = cp.pre.h2_scale;
+                    A.w_gate = ff.gate0; A.s_gate = ff.gate0_scale;
+                } else {
+                    A.h_in = bf.ff_h[(l - 1) & 1]; A.part_in = bf.ff_part[(l - 1) & 1]; A.part_n = G;
+                    A.w_gate = w.in[l].wh2; A.s_gate = w.in[l].h2_scale;
+                }
+                A.part_stride = (long)((size_t)w.H * Ftot);
+                A.h_out = bf.ff_h[l & 1]; A.part_out = bf.ff_part[l & 1];
+                A.macc = bf.ff_macc[cs]; A.macc_stride = (long)hF; A.macc_init = l == 0;
+                A.b_gate = w.in[l].bias;
+                if (w.has_cond) { A.ubias = bt.cond_wn + (size_t)l * 2 * w.H * B; A.ubias_ld = B; }
+                A.w_c = ff.wc[l]; A.s_c = ff.sc[l]; A.rows_c = ff.rows_c[l]; A.rows_res = ff.rows_res[l];
+                A.b_res = ff.b_res[l]; A.b_m = ff.b_m;
+                A.ovf = ovf_;
+                flow_layer(A, stream);
+                if (l == 0 && pend_set >= 0) { cur[x0h] = A.x0_out; pend_set = -1; }
+            }
+            ConvOpt os; os.epi = EPI_SUB;
+            (void)conv_args(cp.post, nullptr, lv1, nullptr, lv1, os, nullptr);
+            pend_set = cs; pend_half = x1h;
+        }
+        if (pend_set >= 0) finish_half(pend_half, pend_set);
+        for (int hh = 0; hh < 2; hh++) if (cur[hh] != home[hh]) finish_half(hh, -1);
+    } else
 #ifdef STS_EXPERIMENTS
     if (use_pk) {
         if (record_taps) { expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream); tap("z_p", bf.z, C, Ftot, Ftot); }

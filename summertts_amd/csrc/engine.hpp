@@ -78,6 +78,8 @@ public:
     int h2_consecutive = 0; bool h2_disabled = false;   // two repeats in a row: the engine stays on split-bf16 until sts_set_conv_math
     double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
+    int flow_fused = 1;                // 1: the reverse flow as one launch per WaveNet layer where eligible (wn_flow.hip; two-term fp16 arithmetic only);
+                                       // 0: one launch per conv (sts_debug_set STS_DBG_FLOW_FUSED)
 #ifdef STS_EXPERIMENTS                 // lab build only (`make exp`): the two persistent-kernel families that lost their A/B
     bool pk_trace = false;             // record the persistent kernel's per-op timeline into taps["pk_trace"] (sts_debug_set)
     int trunk_mode = 0;                // 0 automatic (today: grouped launches), 1 grouped launches, 2 persistent stage kernel where eligible (sts_debug_set)

@@ -191,6 +191,37 @@ bool conv_bf3_stage_eligible(const ConvArgs& a);
 void conv_bf3_stage(const StageArgs& A, hipStream_t st);
 #endif  // STS_EXPERIMENTS
 
+// ---- one launch per WaveNet layer of the reverse flow (wn_flow.hip, round 4).  All intermediate tensors are CHANNEL-MINOR [frame][channel]
+// (packed frames as everywhere else); group g of G = H / Cg handles the gated channels [g Cg, (g + 1) Cg).
+struct FlowLayerArgs {
+    SegView seg; int B, max_len; long tot;      // frame-level segments of the packed batch; tot = frames of the whole batch (buffer extents)
+    int H, half, G, Cg, k, halo;                // WaveNet width, C / 2, channel groups, gate conv taps and (k - 1) / 2
+    int layer;                                  // 0: first layer of a coupling (stages x0, runs `pre` inside the launch)
+    // layer 0: x0 rows (channel-major [half][x0_ld]) + pend_n pending -m slices (channel-minor [frame][half], pend_stride floats apart)
+    // of the previous coupling; their sum is x0' -- written to x0_out (channel-major, another buffer than x0; null: nothing pending)
+    const float* x0; long x0_ld; const float* pend; int pend_n; long pend_stride; float* x0_out; long x0_out_ld;
+    const void* w_pre; const float* b_pre; float s_pre;         // `pre` (1x1, half -> H): two-term fp16 pack (natural k order), bias, 2^-s
+    // layer > 0: h = h_in + part_in[0 .. part_n)   (channel-minor [frame][H], slices part_stride floats apart)
+    const float* h_in; const float* part_in; int part_n; long part_stride;
+    float* h_out;                               // this layer's h (each group writes its channel slice of its own columns)
+    float* part_out;                            // this layer's partial res sums (group g -> slice g), same strides
+    float* macc; long macc_stride; int macc_init;     // -m partial accumulators [frame][half] per group; macc_init: first layer of the coupling
+    const void* w_gate; const float* b_gate; float s_gate;      // gate conv, rows (tanh16, sigmoid16) per 32-row tile; layer 0: perm_k order
+    const float* ubias; int ubias_ld;           // speaker conditioning of the gate rows [2H][B] or null
+    const void* w_c; float s_c; int rows_c, rows_res;           // 1x1 conv on the gated channels (perm_k order, all H channels, chunk-major): rows = [res | -m] padded to 32
+    const float* b_res; const float* b_m;       // biases (added once: by group 0; b_m with macc_init)
+    unsigned* ovf;                              // raised when a staged value leaves the fp16 range
+};
+struct FlowFinishArgs {
+    SegView seg; int B, max_len; int half;
+    const float* src; long src_ld; float* dst; long dst_ld;     // channel-major rows of one half
+    const float* macc; int n; long macc_stride;
+};
+bool flow_layer_shape_ok(int H, int half, int k, int dil, int n_layers);
+int flow_layer_groups(int H);
+void flow_layer(const FlowLayerArgs& a, hipStream_t st);
+void flow_finish(const FlowFinishArgs& a, hipStream_t st);
+
 // ---- launchers (all asynchronous on `st`) ------------------------------------------------------
 // Matrix-core (v_mfma_f32_32x32x2_f32) implicit-GEMM conv.  Returns false when the shape is not
 // eligible (caller then uses conv_generic).  `tile` < 0 picks a tile configuration heuristically.

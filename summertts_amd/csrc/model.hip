@@ -244,6 +244,73 @@ bool pack_k8(Store& st, DConv& d) {
 bool pack_k8(Store&, DConv&) { return true; }     // (only the lab build's persistent flow kernel reads that copy)
 #endif
 
+// Operands of wn_flow.hip for one coupling (see DFlowFused).  post is linear, so m = post(sum_l skip_l) = sum_l (W_post W_skip_l) acts_l + const:
+// the composite matrices are formed in double here, negated (the kernel accumulates -m and ADDS it to x1), and appended to each layer's
+// res rows.  All sources are the already packed fp32 copies, so the coupling's channel reversal (folded into pre / post) is in.
+bool pack_flow_fused(Store& st, DCoupling& c) {
+    DFlowFused& f = c.ff;
+    const DWn& w = c.wn;
+    const int H = w.H, half = c.post.Cout, n = w.n;
+    if (n < 1 || c.pre.Cin != half || c.pre.Cout != H || c.post.Cin != H || !c.pre.wh2 || c.pre.Cin_pad != half) return true;
+    if (!flow_layer_shape_ok(H, half, w.in[0].k, w.in[0].dil, n)) return true;
+    for (int l = 0; l < n; l++) {
+        const DConv &gi = w.in[l], &rs = w.rs[l];
+        if (!gi.gate_perm || gi.Cin != H || gi.Cout != 2 * H || gi.Cin_pad != H || gi.Cout_pad != 2 * H || !gi.wh2 || gi.k != w.in[0].k || gi.dil != 1 || gi.pad != (gi.k - 1) / 2) return true;
+        if (rs.k != 1 || rs.Cin != H || rs.Cin_pad != H || rs.Cout != (l + 1 < n ? 2 * H : H)) return true;
+    }
+    f.G = flow_layer_groups(H); f.Cg = 32;
+    auto host = [&](const float* dptr) { return st.host.data() + (dptr - st.dev); };
+    {   // gate conv of layer 0 in the k order of the parked `pre` output
+        const DConv& gi = w.in[0];
+        const size_t bytes = bf3_pack(nullptr, 1, gi.k, gi.Cin_pad, gi.Cout_pad, nullptr, true, 1);
+        const float* dptr = nullptr;
+        float* p = st.alloc((bytes + 3) / 4 + 1024, &dptr);
+        if (!p) return false;
+        bf3_pack(host(gi.w), 1, gi.k, gi.Cin_pad, gi.Cout_pad, p, true, 1, &f.gate0_scale);
+        f.gate0 = dptr;
+    }
+    const float* wpost = host(c.post.w);                       // [1][H][post.Cout_pad]
+    const int pcp = c.post.Cout_pad;
+    std::vector<double> mb(half, 0.0);
+    for (int cch = 0; cch < half; cch++) mb[cch] = c.post.bias ? (double)host(c.post.bias)[cch] : 0.0;
+    f.wc.assign(n, nullptr); f.sc.assign(n, 1.f); f.rows_c.assign(n, 0); f.rows_res.assign(n, 0); f.b_res.assign(n, nullptr);
+    for (int l = 0; l < n; l++) {
+        const DConv& rs = w.rs[l];
+        const float* wrs = host(rs.w);                         // [1][H][rs.Cout_pad]: rows 0..H-1 res (layers before the last), then skip
+        const float* brs = rs.bias ? host(rs.bias) : nullptr;
+        const int rows_res = l + 1 < n ? H : 0, skip0 = l + 1 < n ? H : 0;
+        const int rows_c = round_up(rows_res + half, 32);
+        std::vector<float> m((size_t)H * rows_c, 0.f);         // [ci][row]
+        for (int ci = 0; ci < H; ci++) {
+            for (int r = 0; r < rows_res; r++) m[(size_t)ci * rows_c + r] = wrs[(size_t)ci * rs.Cout_pad + r];
+            for (int cch = 0; cch < half; cch++) {
+                double acc = 0.0;
+                for (int j = 0; j < H; j++) acc += (double)wpost[(size_t)j * pcp + cch] * (double)wrs[(size_t)ci * rs.Cout_pad + skip0 + j];
+                m[(size_t)ci * rows_c + rows_res + cch] = (float)(-acc);
+            }
+        }
+        if (brs) for (int cch = 0; cch < half; cch++) { double acc = 0.0; for (int j = 0; j < H; j++) acc += (double)wpost[(size_t)j * pcp + cch] * (double)brs[skip0 + j]; mb[cch] += acc; }
+        const size_t bytes = bf3_pack(nullptr, 1, 1, H, rows_c, nullptr, true, 1);
+        const float* dptr = nullptr;
+        float* p = st.alloc((bytes + 3) / 4 + 1024, &dptr);
+        if (!p) return false;
+        bf3_pack(m.data(), 1, 1, H, rows_c, p, true, 1, &f.sc[l]);
+        f.wc[l] = dptr; f.rows_c[l] = rows_c; f.rows_res[l] = rows_res;
+        if (rows_res && brs) {
+            float* b = st.alloc(round_up(H, 4) + 4, &f.b_res[l]);
+            if (!b) return false;
+            memcpy(b, brs, sizeof(float) * H);
+        }
+    }
+    {
+        float* b = st.alloc(round_up(half, 4) + 4, &f.b_m);
+        if (!b) return false;
+        for (int cch = 0; cch < half; cch++) b[cch] = (float)(-mb[cch]);
+    }
+    f.ok = true;
+    return true;
+}
+
 // extra copy of a square 1x1 conv in the fused column-block kernel's operand order (col_layer.hip)
 bool pack_col(Store& st, const HConv& h, DConv& d, int out_rows = -1) {
     const int rows = out_rows > 0 ? out_rows : h.out_ch;
@@ -521,6 +588,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         HConv post = parse_conv(r);
         if (!r.ok || post.k != 1 || post.out_ch != m.inter / 2 || post.in_ch != w.H || pre.out_ch != w.H) FAIL("coupling post");
         { PackOpts o; o.reverse_out = c.flipped; if (!pack_conv(st, post, o, c.post) || !pack_bf3(st, c.post) || !pack_k8(st, c.post)) FAIL("coupling post pack"); }
+        if (!pack_flow_fused(st, c)) FAIL("coupling fused-layer pack");
     }
 
     // ---- duration predictor

@@ -57,7 +57,16 @@ struct DMha { int ch = 0, kc = 0, win = 0, px = 0; const float* relk = nullptr; 
 struct DFfn { int ksize = 1; DConv c1, c2; };
 struct DResBlock { std::vector<DConv> c1, c2; };
 struct DWn { int n = 0, H = 0; std::vector<DConv> in, rs; bool has_cond = false; DConv cond; };
-struct DCoupling { DConv pre, post; DWn wn; bool flipped = false; };
+// operands of the one-launch-per-layer flow kernel (wn_flow.hip; model.hip pack_flow_fused): the first layer's gate weights in the k order
+// of a parked accumulator, and per layer the 1x1 conv on the gated channels with rows [res | -(W_post W_skip_l)] (two-term fp16, perm_k)
+struct DFlowFused {
+    bool ok = false; int G = 0, Cg = 32;
+    const void* gate0 = nullptr; float gate0_scale = 1.f;
+    std::vector<const void*> wc; std::vector<float> sc; std::vector<int> rows_c, rows_res;
+    std::vector<const float*> b_res;          // res bias per layer (null on the last)
+    const float* b_m = nullptr;               // -(b_post + W_post sum_l b_skip_l)
+};
+struct DCoupling { DConv pre, post; DWn wn; bool flipped = false; DFlowFused ff; };
 struct DDds { int n = 0; std::vector<DConv> sep, pw; std::vector<DLn> n1, n2; };
 struct DConvFlow { DConv pre, proj; DDds dds; int filter = 0; };
 
