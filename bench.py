@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak (~2.5 PF; 2495 measured)
 BF16_PRODUCTS_PER_F32 = 6       # conv_bf3.hip: six bf16 products per fp32 product (operands split into three bf16 terms)
+SUSTAINED_F16_TWO_TERM_TFLOPS = 1490.0   # the same for the 12-MFMA sequence of the two-term fp16 form (profiles/r03_f16x2_kloop_decomposition.log / tools/ubench/run_peaks.py)
 SUSTAINED_BF16_SPLIT_TFLOPS = 1712.0   # tools/ubench/mfma_bf16_peak.hip on MI355X (profiles/r02_mfma_bf16_peak_ubench.log): what a bare loop of
                                        # the kernel's MFMA sequence sustains on the hi/mid/lo planes of random fp32 data (data-dependent DVFS)
 PEAK_HBM_GBS = 8000.0
@@ -268,6 +269,12 @@ def main():
     ap.add_argument("--cpu-threads", default="8,16,32,64", help="OpenMP thread counts tried once for the CPU baseline")
     ap.add_argument("--cpu-sample-phonemes", type=int, default=0, help="0 = the GPU step's utterance (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-utt", default="auto", choices=["auto", "first", "shortest"],
+                    help="which utterance of the timed step the CPU baseline (and `parity`) runs: auto = the first one at batch 1, the shortest one "
+                         "of a batch (a bounded sample: the reference needs ~0.2 s per phoneme)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="after the K timed steps, keep stepping for at least this long and report that leg as `sustained` (the K-step burst of a "
+                         "3 ms step lasts 60 ms: boost clocks; 0 = off)")
     ap.add_argument("--conv-mode", type=int, default=0)
     ap.add_argument("--conv-math", default=_env_conv_math(), choices=["bf16x3", "f32", "f16x2"],
                     help="arithmetic of the decoder trunk convs: f16x2 (default) = fp32 operands as two fp16 terms, three fp16 MFMA products per "
@@ -425,18 +432,40 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     last = syn.profile()
+    # ---- the same step for at least --min-seconds more: what the box sustains once clocks and temperatures have settled
+    sustained = None
+    if args.min_seconds > 0 and dist is None and not stub:
+        ts0 = time.perf_counter()
+        ns, ssamp = 0, 0
+        while time.perf_counter() - ts0 < args.min_seconds:
+            n, _pcm = step()
+            ssamp += n
+            ns += 1
+        if use_cuda:
+            torch.cuda.synchronize()
+        se = time.perf_counter() - ts0
+        sustained = {"seconds": se, "steps": ns, "ms_per_step": 1e3 * se / max(1, ns), "value": ssamp / se, "unit": "samples/s",
+                     "x_realtime_16khz": ssamp / se / 16000.0,
+                     "note": "back-to-back steps right after the K timed ones, same process, same engine; `value` of the line stays the K-step figure the contract defines"}
+
+    # the utterance of the step that the reference is run on (CPU baseline + parity)
+    cpu_u = 0
+    if ids and (args.cpu_sample_utt == "shortest" or (args.cpu_sample_utt == "auto" and len(ids) > 1)):
+        cand = [u for u in range(len(ids)) if sid[u] == 0] or list(range(len(ids)))
+        cpu_u = min(cand, key=lambda u: len(ids[u]))
 
     def capture_output():
-        """One extra UNTIMED run of the step with the float-waveform tap on: utterance 0's durations / PCM / waveform, to be compared
+        """One extra UNTIMED run of the step with the float-waveform tap on: utterance cpu_u's durations / PCM / waveform, to be compared
         with the reference's output for the same blob and ids (parity_report)."""
         if stub or dist is not None or not ids or not hasattr(syn, "set_record_taps"):
             return None
         try:
             syn.set_record_taps(True)
-            n_out = syn.run_batch(ids, sid, ls)
-            n0, t0_ = int(n_out[0]), len(ids[0])
-            got = {"pcm": syn.pcm_host()[:n0].copy(), "durations": syn.durations(sum(len(a) for a in ids))[:t0_].copy(),
-                   "wave": syn.tap("wave")[0][:n0].copy()}
+            n_out = [int(v) for v in syn.run_batch(ids, sid, ls)]
+            s0, t0_ = sum(n_out[:cpu_u]), sum(len(a) for a in ids[:cpu_u])
+            got = {"pcm": syn.pcm_host()[s0:s0 + n_out[cpu_u]].copy(),
+                   "durations": syn.durations(sum(len(a) for a in ids))[t0_:t0_ + len(ids[cpu_u])].copy(),
+                   "wave": syn.tap("wave")[0][s0:s0 + n_out[cpu_u]].copy()}
             return got
         except Exception as e:
             return {"error": str(e)}
@@ -618,10 +647,12 @@ def main():
                 "achieved_definition": "ALGORITHMIC (direct-form, true-tap) fp32 FLOPs of the launches / their HIP-event time: the task's "
                                        "roofline figure (SURVEY.md 8d).  It is an effective rate, not pipe utilisation -- see *_issued_*",
                 "sustained_mfma_ceiling": (dict(ceiling, frac=achieved_tf / ceiling["tflops_fp32_equivalent"], measured=True) if ceiling else
-                                           {"tflops_fp32_equivalent": SUSTAINED_BF16_SPLIT_TFLOPS / products,
-                                            "frac": achieved_tf / (SUSTAINED_BF16_SPLIT_TFLOPS / products), "measured": False,
-                                            "source": "tools/ubench/libsts_ubench.so not built: constant from profiles/r02_mfma_bf16_peak_ubench.log "
-                                                      "(1712 bf16 TF/s of the nominal 2500)"}) if split else None,
+                                           {"tflops_fp32_equivalent": (SUSTAINED_F16_TWO_TERM_TFLOPS if products == 3 else SUSTAINED_BF16_SPLIT_TFLOPS) / products,
+                                            "frac": achieved_tf / ((SUSTAINED_F16_TWO_TERM_TFLOPS if products == 3 else SUSTAINED_BF16_SPLIT_TFLOPS) / products),
+                                            "measured": False,
+                                            "source": "tools/ubench/libsts_ubench.so not built: the constant of the arithmetic that ran ("
+                                                      + ("1490 fp16 TF/s on two-term planes, round 3" if products == 3 else "1712 bf16 TF/s on three-term planes, round 2")
+                                                      + " of the nominal 2500)"}) if split else None,
                 "bf16_issued_tflops": bf16_tf,
                 "bf16_issued_frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
                 "bf16_issued_definition": "bf16 matrix-core FLOPs the split-operand launches issue (6 x their algorithmic FLOPs; 3 x under f16x2) / the same "
@@ -654,19 +685,23 @@ def main():
             out["bf16x3_leg"] = bf3_leg
         if pipelined is not None:
             out["request_pool"] = pipelined
+        if sustained is not None:
+            out["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline and not stub:
             try:
-                cpu_T = args.cpu_sample_phonemes or (len(ids[0]) if ids else args.phonemes)
-                cpu_ids = ids[0] if (ids and cpu_T == len(ids[0])) else sb.synthetic_ids(cpu_T, cfg.vocab)
+                cpu_T = args.cpu_sample_phonemes or (len(ids[cpu_u]) if ids else args.phonemes)
+                cpu_ids = ids[cpu_u] if (ids and cpu_T == len(ids[cpu_u])) else sb.synthetic_ids(cpu_T, cfg.vocab)
                 ref_out, out["cpu_baseline"] = cpu_baseline(blob, cfg.vocab, cpu_ids, args.cpu_reps,
                                                             [int(x) for x in args.cpu_threads.split(",") if x])
-                # parity of the PUBLISHED workload, in the line that publishes it: the reference's output for utterance 0 of this
+                if out["cpu_baseline"] is not None:
+                    out["cpu_baseline"]["sample_utterance"] = f"utterance {cpu_u} of the timed step ({len(cpu_ids)} phonemes)"
+                # parity of the PUBLISHED workload, in the line that publishes it: the reference's output for one utterance of this
                 # very step (same blob, same ids) against the GPU output of every timed leg
-                if ref_out is not None and ids and cpu_ids is ids[0] and sid[0] == 0:
+                if ref_out is not None and ids and cpu_ids is ids[cpu_u] and sid[cpu_u] == 0:
                     par = {}
                     for leg, g in gpu_out.items():
                         par[leg] = g if (g is None or "error" in g) else parity_report(ref_out, g)
-                    par["checked"] = (f"utterance 0 of the timed step ({len(cpu_ids)} phonemes, speaker 0) vs the compiled reference "
+                    par["checked"] = (f"utterance {cpu_u} of the timed step ({len(cpu_ids)} phonemes, speaker 0) vs the compiled reference "
                                       "(oracle/_ref) on the same blob and ids; tolerance: durations equal, PCM <= 1 LSB, wave RMSE <= 2e-6")
                     out["parity"] = par
             except Exception as e:   # the baseline must never take the GPU number down with it

@@ -161,13 +161,13 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     if (a.max_n <= 0 || a.B <= 0) return;
     if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
-    if (a.nsum >= 2 && tile != 0 && tile != 20 && tile != 22 && tile != 23) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
+    if (a.nsum >= 2 && tile != 22 && tile != 23) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
     switch (tile) {
-        case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2, true, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true, true>(a, nphase, st); break;
+        case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         // phase-merged rows (transposed convs): 22: 128 x 128   23: 64 x 128 as two 32-row waves x 2   (lab: 21: 256 x 128, 8 waves)
         case 22: launch_bf3<2, 2, 2, 2, 1, 1, true, true>(a, nphase, st, 1); break;
         case 23: launch_bf3<1, 2, 2, 2, 1, 1, true, true>(a, nphase, st, 1); break;
-        case 0: launch_bf3<2, 2, 2, 2, 1, 1, true, true>(a, nphase, st); break;
+        case 0: launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         case 3: launch_bf3<2, 2, 1, 2, 1, 1, true>(a, nphase, st); break;
 #ifdef STS_EXPERIMENTS      // tiles no automatic choice selects (measured ties / losses, profiles/r03_*tile_sweep.log): lab build only
         case 24: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 4, 1, 2, 2, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
