@@ -132,6 +132,7 @@ int sts_set_conv_math(sts_engine* e, int mode);
  *   (0, 1) and answers STS_EINVAL to 2. */
 enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2, STS_DBG_PK_TRACE = 3 /* per-op timeline of the persistent kernel -> tap "pk_trace" */,
        STS_DBG_TRUNK_MODE = 4 /* 128-channel decoder stage of a one-utterance call: 0 automatic, 1 grouped launches, 2 one persistent launch per stage */,
+       STS_DBG_LAUNCH_AHEAD = 6 /* one-utterance calls: 1 (default) flow + decoder are enqueued for a predicted frame capacity before the count reaches the host, 0 the host waits for it */,
        STS_DBG_FLOW_FUSED = 5 /* reverse flow: 1 (default) one launch per WaveNet layer (wn_flow.hip, under the two-term fp16 arithmetic), 0 one launch per conv */ };
 int sts_debug_set(sts_engine* e, int key, int value);
 
@@ -152,14 +153,15 @@ typedef struct sts_profile {
                                              (6 x their algorithmic FLOPs; 3 x with sts_set_conv_math(3)); 0 with sts_set_conv_math(1) */
     int64_t conv_math_fallbacks;          /* sts_set_conv_math(3): calls of this engine so far that were repeated in the split-bf16 form */
     int32_t conv_math_pinned;             /* 1: after two such calls in a row the engine now stays in the split-bf16 form (until sts_set_conv_math) */
-    int32_t reserved0;
+    int32_t launch_ahead;                 /* 1: this run enqueued flow + decoder before the frame count reached the host (one utterance; ms_sync_wait_host ~ 0) */
+    int64_t launch_ahead_misses;          /* launch-ahead runs of this engine so far whose predicted frame capacity was too small (flow + decoder repeated) */
 } sts_profile;
 int sts_set_profiling(sts_engine* e, int enable);
 /* The struct only ever grows at its end (STS_ABI_VERSION counts the revisions).  sts_get_profile_ex copies min(size_bytes,
  * sizeof(sts_profile)) bytes, so a client compiled against an older header passes ITS sizeof and is never overrun;
  * sts_get_profile(e, p) == sts_get_profile_ex(e, p, sizeof(sts_profile)) of the header this library was built from -- use it only
  * when client and library are built together. */
-#define STS_ABI_VERSION 4
+#define STS_ABI_VERSION 5
 int sts_abi_version(void);
 /* bit 0: lab build (-DSTS_EXPERIMENTS: environment knobs of knobs.hpp, the persistent-kernel families, every conv tile code);
  * 0 for the shipped library */

@@ -157,9 +157,10 @@ ConvArgs Engine::conv_args(const DConv& c, const float* x, const Lvl& lin, float
     flops_[cur_stage_] += fl;
     {   // algorithmic HBM bytes: input once, output once, weights once (+ residual / read-modify-write operands)
         const size_t wfl = c.depthwise ? (size_t)c.k * c.Cout : (size_t)c.k * c.Cin * c.Cout;
-        double by = 4.0 * ((double)c.Cin * lin.total + (double)c.Cout * lout.total + (double)wfl);
+        double by = 4.0 * ((double)c.Cin * lin.total + (double)c.Cout * lout.total);
         if (o.res || o.epi == EPI_SUB || o.epi == EPI_RESSKIP) by += 4.0 * (double)c.Cout * lout.total;
-        bytes_[cur_stage_] += by;
+        bytes_[cur_stage_] += by;                         // (scales with the positions)
+        bytes_w_[cur_stage_] += 4.0 * (double)wfl;        // (does not)
     }
     if (flops) *flops = fl;
     return a;
@@ -422,6 +423,11 @@ struct Engine::RunCtx {
     int *d_offT = nullptr, *d_lenT = nullptr, *d_sid = nullptr, *d_offF = nullptr, *d_lenF = nullptr, *d_one = nullptr, *d_win = nullptr;
     bool inl = false, no_inline_seg = false, ms = false;
     long Ftot = 0; int maxF = 0, hop = 0;
+    // One utterance (the reference's own call shape): buffers, leading dimensions and every dispatch decision use the frame CAPACITY
+    // Fld = the count rounded up to a bucket of 64 frames, so that a call which launches the flow and the decoder AHEAD of the frame count
+    // (ahead: the count is predicted, the kernels read the real one from device memory) makes exactly the dispatch decisions of a call
+    // that waited for it -- and returns bit-identical samples.  Batches: Fld == Ftot, nothing changes.
+    long Fld = 0; int maxFld = 0; bool ahead = false, mapped = false;
     int halo = 0; long Wcap = 0; int upS = 1; long Lsb = 0; int sbC = 0;
     bool use_pk = false; int pk_fs = 0, pk_wld = 0, pk_rows = 0;
     bool use_ff = false; int ffG = 0;
@@ -439,6 +445,7 @@ struct Engine::RunCtx {
     [[maybe_unused]] int* const d_win = (c).d_win;                                                                                  \
     [[maybe_unused]] const bool inl = (c).inl, no_inline_seg = (c).no_inline_seg, ms = (c).ms;                                      \
     [[maybe_unused]] const long Ftot = (c).Ftot; [[maybe_unused]] const int maxF = (c).maxF, hop = (c).hop;                         \
+    [[maybe_unused]] const long Fld = (c).Fld; [[maybe_unused]] const int maxFld = (c).maxFld; [[maybe_unused]] const bool ahead = (c).ahead; \
     [[maybe_unused]] const int halo = (c).halo; [[maybe_unused]] const long Wcap = (c).Wcap, Lsb = (c).Lsb;                         \
     [[maybe_unused]] const int upS = (c).upS, sbC = (c).sbC;                                                                        \
     [[maybe_unused]] const bool use_ff = (c).use_ff; [[maybe_unused]] const int ffG = (c).ffG;                                      \
@@ -509,6 +516,7 @@ int Engine::run_setup(RunCtx& c) {
     c.p_offF = pm + 3 * B; c.p_lenF = pm + 4 * B;
     for (int b = 0; b < B; b++) { p_offT[b] = offT[b]; p_lenT[b] = lenT[b]; p_sid[b] = sid ? sid[b] : 0; }
     p_one[0] = 0; p_one[1] = B;
+    if (B == 1) { int* pw0 = pm + 5 * B + 2; c.p_offF[0] = 0; c.p_lenF[0] = 0; pw0[0] = 0; pw0[1] = 0; pw0[2] = 0; }   // (a launch-ahead run: the durations kernel fills the two lengths on the device)
     int* d_offT = c.d_offT = bt.meta_i, *d_lenT = c.d_lenT = bt.meta_i + B, *d_one = c.d_one = bt.meta_i + 5 * B;
     c.d_sid = bt.meta_i + 2 * B; c.d_offF = bt.meta_i + 3 * B; c.d_lenF = bt.meta_i + 4 * B; c.d_win = bt.meta_i + 5 * B + 2;
     float* p_ls = (float*)(pm + meta_ints);
@@ -677,16 +685,42 @@ int Engine::run_durations(RunCtx& c) {
         else { if (hmap_) (void)hipHostFree(hmap_); hmap_ = nullptr; hmap_dev_ = nullptr; }
         if (!arrive_ && hipMalloc((void**)&arrive_, 64) == hipSuccess) (void)hipMemsetAsync(arrive_, 0, 64, stream);
     }
-    const bool mapped = !no_mapped && hmap_ && arrive_;
+    const bool mapped = c.mapped = !no_mapped && hmap_ && arrive_;
     if (mapped) { seq_ = seq_ == 0x7fffffff ? 1 : seq_ + 1; }
+    // Launch-ahead (one utterance, plain call): the flow and the decoder are enqueued for a PREDICTED frame capacity -- the largest count
+    // an utterance of this many phonemes has produced on this engine, in buckets of 64 frames -- and read the real count from device
+    // memory, where the durations kernel leaves it (clamped to the capacity).  The host never waits between the duration predictor and the
+    // flow; it reads the count after the last kernel is enqueued, sizes the PCM download with it, and repeats flow + decoder the
+    // waiting way in the rare case that the count exceeded the capacity.
+    long pred = 0;
+    if (launch_ahead && B == 1 && !ss && !have_forced && !record_taps && mapped)
+        for (const auto& tf : seen_tf_) if (tf.first == (int)Ttot && tf.second > pred) pred = tf.second;
+    c.ahead = pred > 0;
+    c.hop = M.hop_total;
+    const long cap = c.ahead ? (pred + 63) / 64 * 64 : 0;
     durations(r_final, M.dur_type == 0 ? 1 : 0, M.ea_m, M.ea_logs, bt.ls, have_forced ? bt.forced : nullptr, bt.dlogw,
-              bt.dur, bt.cum, bt.frames, lvT.seg, B, stream, mapped ? hmap_dev_ : nullptr, Ttot, seq_, arrive_);
+              bt.dur, bt.cum, bt.frames, lvT.seg, B, stream, mapped ? hmap_dev_ : nullptr, Ttot, seq_, arrive_,
+              c.ahead ? c.d_lenF : nullptr, c.ahead ? c.d_win + 2 : nullptr, (int)cap);
     have_forced = false;
     mark(2);
-    int* p_down = (int*)(pinned_ + up_bytes);
+    sync_wait_ms_ = 0;
+    if (c.ahead) {
+        c.Ftot = cap; c.maxF = (int)cap;                // (capacity; the real count replaces it in run_output)
+        return frame_geometry(c);
+    }
+    int rc = wait_frame_counts(c);
+    if (rc != STS_OK) return rc;
+    return frame_geometry(c);
+}
+
+// blocks until the durations kernel's results are on the host: durations_h, per-utterance frame offsets / counts, Ftot, maxF
+int Engine::wait_frame_counts(RunCtx& c) {
+    const int B = c.B; const long Ttot = c.Ttot; BufT& bt = c.bt;
+    int* const p_offF = c.p_offF; int* const p_lenF = c.p_lenF;
+    int* p_down = (int*)(pinned_ + c.up_bytes);
     {
         const auto w0 = std::chrono::steady_clock::now();
-        if (mapped) {
+        if (c.mapped) {
             volatile int* flag = hmap_;                 // word 0 = sequence flag, then dur[Ttot], frames[B]
             bool ok = false;
             // a short pure spin (the usual wait is a fraction of a millisecond), then polite polling -- pool / multi-device
@@ -712,27 +746,41 @@ int Engine::run_durations(RunCtx& c) {
             HIPCK(hipMemcpyAsync(p_down, bt.dur, ((size_t)Ttot + B) * 4, hipMemcpyDeviceToHost, stream));
             HIPCK(hipStreamSynchronize(stream));
         }
-        sync_wait_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        sync_wait_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     }
     durations_h.assign(p_down, p_down + Ttot);
     tap("logw", bt.dlogw, 1, Ttot, Ttot);
-    long& Ftot = c.Ftot; int& maxF = c.maxF;
-    Ftot = 0; maxF = 0;
+    c.Ftot = 0; c.maxF = 0;
     for (int b = 0; b < B; b++) {
         int f = p_down[Ttot + b];
-        p_offF[b] = (int)Ftot; p_lenF[b] = f; Ftot += f; if (f > maxF) maxF = f;
+        p_offF[b] = (int)c.Ftot; p_lenF[b] = f; c.Ftot += f; if (f > c.maxF) c.maxF = f;
     }
+    if (B == 1) {      // what an utterance of this length needs: the launch-ahead capacity of later calls
+        bool found = false;
+        for (auto& tf : seen_tf_) if (tf.first == (int)Ttot) { if (c.Ftot > tf.second) tf.second = c.Ftot; found = true; }
+        if (!found) { if (seen_tf_.size() >= 64) seen_tf_.erase(seen_tf_.begin()); seen_tf_.emplace_back((int)Ttot, c.Ftot); }
+    }
+    return STS_OK;
+}
+
+// frame capacity (one utterance: buckets of 64 frames), geometry tables on the device, room for the PCM download
+int Engine::frame_geometry(RunCtx& c) {
+    Model& M = model;
+    const int B = c.B; const StreamSpec* const ss = c.ss;
+    int* const pm = c.pm; int* const p_offF = c.p_offF; int* const p_lenF = c.p_lenF;
     const int hop = c.hop = M.hop_total;
-    if ((double)Ftot * hop > 2.0e9 || (double)Ftot * hop * 8 > 6.0e10) return fail(STS_EINVAL, "batch produces too many samples for one call");
-    {   // frame geometry + (normal call) the decode windows = the utterances, in the same copy
+    c.Fld = (B == 1 && !ss) ? (c.Ftot + 63) / 64 * 64 : c.Ftot;
+    c.maxFld = (B == 1 && !ss) ? (int)c.Fld : c.maxF;
+    if ((double)c.Fld * hop > 2.0e9 || (double)c.Fld * hop * 8 > 6.0e10) return fail(STS_EINVAL, "batch produces too many samples for one call");
+    if (!c.ahead) {   // frame geometry + (normal call) the decode windows = the utterances, in the same copy
         int* pw = pm + 5 * B + 2;
         for (int b = 0; b < B; b++) { pw[b] = p_offF[b]; pw[B + b] = p_offF[b]; pw[2 * B + b] = p_lenF[b]; }
         // (a single utterance carries its geometry in the kernel arguments: nothing on the device reads these tables)
-        if (!inl || ss) HIPCK(hipMemcpyAsync(d_offF, p_offF, (size_t)(5 * B + 2) * 4, hipMemcpyHostToDevice, stream));
+        if (!c.inl || ss) HIPCK(hipMemcpyAsync(c.d_offF, p_offF, (size_t)(5 * B + 2) * 4, hipMemcpyHostToDevice, stream));
     }
     h_pcm = nullptr;
     if (host_pcm && !ss) {   // room for the PCM download that rides at the end of this run
-        const size_t need = (size_t)Ftot * hop * 2 + 256;
+        const size_t need = (size_t)c.Fld * hop * 2 + 256;
         if (need > pinned_pcm_cap_) {
             if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
             pinned_pcm_ = nullptr; pinned_pcm_cap_ = 0;
@@ -740,14 +788,14 @@ int Engine::run_durations(RunCtx& c) {
             pinned_pcm_cap_ = need + need / 2;
         }
     }
-
     return STS_OK;
 }
 
 // ---- stage 3: frame-level workspace (flow buffers over all frames, decoder buffers over the decode windows)
 int Engine::run_frame_workspace(RunCtx& c) {
     Model& M = model;
-    const int B = c.B; const StreamSpec* const ss = c.ss; const long Ftot = c.Ftot; const int maxF = c.maxF, hop = c.hop;
+    const int B = c.B; const StreamSpec* const ss = c.ss; const int hop = c.hop;
+    const long Ftot = c.Fld; const int maxF = c.maxFld;        // (capacity: == the counts except for one utterance, see RunCtx::Fld)
     const int C = c.C, wnH = c.wnH; const bool inl = c.inl;
     int* const p_lenF = c.p_lenF; int* const d_offF = c.d_offF; int* const d_lenF = c.d_lenF;
     // ---------------- frame-level workspace.  The flow works on all Ftot frames; the decoder works on
@@ -769,8 +817,8 @@ int Engine::run_frame_workspace(RunCtx& c) {
     // round trips, partial-sum exchange, store acknowledgement, completion poll) and the gate convs are fp32-MFMA-bound on windows
     // that overlap 1.77x -- so the launch-per-layer path stays the default and this one is opt-in: front_mode 2 (sts_debug_set)
 #ifdef STS_EXPERIMENTS
-    const bool use_pk = c.use_pk = B == 1 && !M.cp.empty() && front_mode == 2 && conv_mode == 0 && conv_math != 2 && Ftot <= 16384 && flow_program();
-    const int pk_fs = c.pk_fs = (int)((Ftot + 7) / 8);
+    const bool use_pk = c.use_pk = B == 1 && !c.ahead && !M.cp.empty() && front_mode == 2 && conv_mode == 0 && conv_math != 2 && c.Ftot <= 16384 && flow_program();
+    const int pk_fs = c.pk_fs = (int)((c.Ftot + 7) / 8);
     const int pk_wld = c.pk_wld = (pk_fs + 2 * pk_halo_ + 31) / 32 * 32 + 32;
     const int pk_rows = c.pk_rows = C > wnH ? C : wnH;
 #else
@@ -785,7 +833,8 @@ int Engine::run_frame_workspace(RunCtx& c) {
         // one round of workgroups at most: a workgroup re-pulls its group's ~290 KB of weights for 32 frames, which pays while the launch
         // is latency-bound (668 frames: 0.31 vs 0.45 ms) and loses by 2.6x once it is not (batch 32: 7.3 vs 2.8 ms; profiles/r04_ab_log.md)
         long tiles = 0;
-        for (int b = 0; b < B; b++) tiles += (p_lenF[b] + 31) / 32;
+        if (B == 1) tiles = (Ftot + 31) / 32;
+        else for (int b = 0; b < B; b++) tiles += (p_lenF[b] + 31) / 32;
         use_ff = tiles * M.cp[0].ff.G <= 256;
     }
     c.use_ff = use_ff; c.ffG = use_ff ? M.cp[0].ff.G : 0;
@@ -818,7 +867,7 @@ int Engine::run_frame_workspace(RunCtx& c) {
     if (!ensure(arenaF_, arenaF_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (frame-level workspace)");
     arenaF_.measuring = false; layoutF(arenaF_);
 
-    Lvl& lv1 = c.lv1; lv1 = Lvl(); lv1.seg = inl ? SegView{nullptr, nullptr, 1, 0, 0, p_lenF[0]} : SegView{d_offF, d_lenF, 1, 0, 0, 0};
+    Lvl& lv1 = c.lv1; lv1 = Lvl(); lv1.seg = (inl && !c.ahead) ? SegView{nullptr, nullptr, 1, 0, 0, p_lenF[0]} : SegView{d_offF, d_lenF, 1, 0, 0, 0};
     lv1.nb = B; lv1.max_len = maxF; lv1.total = Ftot; lv1.ld = Ftot;
     mark(7);
     (void)pk_fs; (void)pk_wld; (void)pk_rows;
@@ -828,12 +877,15 @@ int Engine::run_frame_workspace(RunCtx& c) {
 // ---- stage 4: length regulator + reverse flow
 int Engine::run_flow(RunCtx& c) {
     RUN_ALIASES(c)
+    const long Fcount = c.Ftot;         // frames of the batch (taps); below, Ftot / maxF are the CAPACITY the buffers and launches are sized for
+#define Ftot Fld
+#define maxF maxFld
     // ---------------- length regulator (SynthesizerTrn.cpp:304-321, 380-383: z_p == m_expand, noise 0)
     stage_begin(2);
     const int half = C / 2;
     if (use_ff) {
         expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream);
-        tap("z_p", bf.z, C, Ftot, Ftot);
+        tap("z_p", bf.z, C, Ftot, Fcount);
         const int G = ffG;
         const size_t hF = (size_t)half * Ftot;
         // where the newest version of each half of z lives: z itself, or the alternate buffer (a first layer that applies the previous
@@ -902,7 +954,7 @@ int Engine::run_flow(RunCtx& c) {
     } else
 #ifdef STS_EXPERIMENTS
     if (use_pk) {
-        if (record_taps) { expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream); tap("z_p", bf.z, C, Ftot, Ftot); }
+        if (record_taps) { expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream); tap("z_p", bf.z, C, Ftot, Fcount); }
         const long cstride = (long)((2 * wnH * wnL + 3) & ~3);
         for (int i = M.n_flows - 1; i >= 0; i--) {        // speaker conditioning of every coupling up front + the stage's FLOP / byte account
             const DCoupling& cp = M.cp[i];
@@ -922,7 +974,7 @@ int Engine::run_flow(RunCtx& c) {
         memset(&P, 0, sizeof(P));
         P.prog = pk_prog_; P.nsteps = pk_nsteps_;
         P.m = bt.m; P.m_ld = Ttot; P.cum = bt.cum; P.T = (int)Ttot;
-        P.z = bf.z; P.z_ld = Ftot; P.F = (int)Ftot; P.C = C;
+        P.z = bf.z; P.z_ld = Ftot; P.F = (int)Fcount; P.C = C;
         P.priv = bf.pk; P.priv_stride = (long)4 * pk_rows * pk_wld; P.wld = pk_wld; P.rows = pk_rows;
         P.fs = pk_fs; P.halo_total = pk_halo_;
         P.cond = bt.cond_wn; P.ctr = pk_ctr_;
@@ -954,7 +1006,7 @@ int Engine::run_flow(RunCtx& c) {
 #endif
     {
     expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream);
-    tap("z_p", bf.z, C, Ftot, Ftot);
+    tap("z_p", bf.z, C, Ftot, Fcount);
 
     // ---------------- reverse flow (ResidualCouplingBlock.cpp:59-70, ResidualCouplingLayer.cpp:47-66, WN.cpp:100-149)
     for (int i = M.n_flows - 1; i >= 0; i--) {
@@ -977,9 +1029,11 @@ int Engine::run_flow(RunCtx& c) {
     }
     }
     if (M.n_flows & 1) flip_channels(bf.z, Ftot, C, Ftot, bf.fliptmp, stream);
-    tap("z", bf.z, C, Ftot, Ftot);
+    tap("z", bf.z, C, Ftot, Fcount);
     mark(3);
     return STS_OK;
+#undef Ftot
+#undef maxF
 }
 
 #ifdef STS_EXPERIMENTS   // lab build only: a tie with the grouped launches
@@ -1111,18 +1165,19 @@ bool Engine::stage_persistent(RunCtx& c, int i, const float* bup, const Lvl& l2,
 // and owns the compact range starting at coff[w] in every decoder buffer.  (Normal call: the windows ARE the
 // utterances and zoff == coff == offF.)  d_win = device ints {zoff[nw], coff[nw], wlen[nw]}.
 // (zoff0 = frame offset of window 0 inside z: the by-value form of a single window)
-int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
+int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wlen0) {
     RUN_ALIASES(c)
     stage_begin(3);
-    const bool winl = nw == 1 && !no_inline_seg;
+    // (wlen0: real length of a single window, by value; < 0: the windows' geometry is read from the device tables)
+    const bool winl = nw == 1 && !no_inline_seg && wlen0 >= 0;
     auto lvF = [&](int scale, int extra) {
-        Lvl l; l.seg = winl ? SegView{nullptr, nullptr, scale, extra, 0, maxW} : SegView{d_win + nw, d_win + 2 * nw, scale, extra, 0, 0};
+        Lvl l; l.seg = winl ? SegView{nullptr, nullptr, scale, extra, 0, wlen0} : SegView{d_win + nw, d_win + 2 * nw, scale, extra, 0, 0};
         l.nb = nw; l.max_len = maxW * scale + extra;
         l.total = Wtot * scale + (long)nw * extra; l.ld = l.total;
         return l;
     };
-    Lvl lz; lz.seg = winl ? SegView{nullptr, nullptr, 1, 0, zoff0, maxW} : SegView{d_win, d_win + 2 * nw, 1, 0, 0, 0};
-    lz.nb = nw; lz.max_len = maxW; lz.total = Ftot; lz.ld = Ftot;
+    Lvl lz; lz.seg = winl ? SegView{nullptr, nullptr, 1, 0, zoff0, wlen0} : SegView{d_win, d_win + 2 * nw, 1, 0, 0, 0};
+    lz.nb = nw; lz.max_len = maxW; lz.total = Fld; lz.ld = Fld;
     const Lvl lw1 = lvF(1, 0);
     {
         ConvOpt op;
@@ -1377,7 +1432,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0) {
         flops_[3] += 2.0 * (double)Ntot * (16.0 * 4 + 4 * 18 * 4 / 4.0);
     }
     mark(4);
-    if (wave) tap("wave", wave, 1, Ntot, Ntot);
+    if (wave) tap("wave", wave, 1, Ntot, (wlen0 >= 0 ? (long)wlen0 : Wtot) * hop);
     return STS_OK;
 }
 
@@ -1437,6 +1492,7 @@ int Engine::run_once(int B, const int32_t* const* ids, const int32_t* n, const i
     memset(&prof, 0, sizeof(prof));
     for (double& f : flops_) f = 0;
     for (double& f : bytes_) f = 0;
+    for (double& f : bytes_w_) f = 0;
     mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
 #ifdef STS_EXPERIMENTS
     ps_tab_busy_ = false;          // (the previous run ended with a stream synchronisation)
@@ -1458,24 +1514,48 @@ int Engine::run_once(int B, const int32_t* const* ids, const int32_t* n, const i
 int Engine::run_output(RunCtx& c) {
     RUN_ALIASES(c)
     n_samples.resize(B);
+    if (!ss) {
+        // windows = utterances.  One utterance: by value when its frame count is known, from the device tables in a launch-ahead run
+        int rc = run_decode(c, B, Fld, maxFld, 0, (B == 1 && !ahead) ? (int)Ftot : -1);
+        if (rc != STS_OK) return rc;
+        if (ahead) {
+            // everything is enqueued.  The PCM download is queued for the CAPACITY (<= 63 frames more than needed) and the run's one
+            // stream synchronisation happens before the count is looked at: the host never waits for the count by itself
+            if (host_pcm) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)Fld * hop * 2, hipMemcpyDeviceToHost, stream));
+            HIPCK(hipStreamSynchronize(stream));
+            if ((rc = wait_frame_counts(c)) != STS_OK) return rc;
+            if (c.Ftot > Fld) {
+                // more frames than the capacity this call was launched for (an utterance of this length had never needed as many): the
+                // kernels clamped to the capacity, their output is discarded, and flow + decoder run again the waiting way
+                ahead_misses++;
+                HIPCK(hipStreamSynchronize(stream));
+                c.ahead = false;
+                flops_[2] = flops_[3] = bytes_[2] = bytes_[3] = bytes_w_[2] = bytes_w_[3] = 0;
+                mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+                if ((rc = frame_geometry(c)) != STS_OK) return rc;
+                if ((rc = run_frame_workspace(c)) != STS_OK) return rc;
+                if ((rc = run_flow(c)) != STS_OK) return rc;
+                return run_output(c);
+            }
+        }
+    }
+    const long Fcount = c.Ftot;                // (from here on: the real count)
     for (int b = 0; b < B; b++) n_samples[b] = p_lenF[b] * hop;
     if (!ss) {
-        const int rc = run_decode(c, B, Ftot, maxF, 0);   // windows = utterances (uploaded with the frame geometry)
-        if (rc != STS_OK) return rc;
         d_pcm = bf.pcm;
-        total_samples = Ftot * hop;
+        total_samples = Fcount * hop;
         if (host_pcm) {
-            HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)total_samples * 2, hipMemcpyDeviceToHost, stream));
+            if (!ahead) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)total_samples * 2, hipMemcpyDeviceToHost, stream));
             h_pcm = (const int16_t*)pinned_pcm_;
         }
-        HIPCK(hipStreamSynchronize(stream));
+        if (!ahead) HIPCK(hipStreamSynchronize(stream));
         HIPCK(hipGetLastError());
     } else {
         // Streaming: chunk c = frames [f0, f1) is decoded from the window [f0 - halo, f1 + halo)
         // clipped to the utterance; the halo covers the decoder's receptive field, so the kept samples are
         // computed from exactly the inputs the one-pass decode sees (bit-identical for a pinned kernel variant).  PCM of a chunk goes to the caller before the next chunk starts.
         if (ms && M.dec_type == 0 && B != 1) return fail(STS_EINVAL, "streaming is single-utterance");
-        const long F = Ftot;
+        const long F = Fcount;
         int16_t* hp = nullptr;
         const size_t hp_off = (up_bytes + ((size_t)Ttot + B) * 4 + 255) & ~(size_t)255;
         if (!ensure_pinned(hp_off + (size_t)ss->chunk_frames * hop * 2 + 256)) return fail(STS_EDEVICE, "pinned host allocation failed");
@@ -1488,7 +1568,7 @@ int Engine::run_output(RunCtx& c) {
             const long w0 = std::max<long>(0, f0 - halo), w1 = std::min<long>(F, f1 + halo);
             pw[0] = (int)w0; pw[1] = 0; pw[2] = (int)(w1 - w0);
             HIPCK(hipMemcpyAsync(d_win, pw, 3 * 4, hipMemcpyHostToDevice, stream));
-            const int rc = run_decode(c, 1, w1 - w0, (int)(w1 - w0), (int)w0);
+            const int rc = run_decode(c, 1, w1 - w0, (int)(w1 - w0), (int)w0, (int)(w1 - w0));
             if (rc != STS_OK) return rc;
             const long ns = (f1 - f0) * hop;
             HIPCK(hipMemcpyAsync(hp, bf.pcm + (f0 - w0) * hop, (size_t)ns * 2, hipMemcpyDeviceToHost, stream));
@@ -1505,15 +1585,21 @@ int Engine::run_output(RunCtx& c) {
         }
         HIPCK(hipGetLastError());
     }
-    const long Ntot = Ftot * hop;
+    const long Ntot = Fcount * hop;
+    // one utterance: the launches were sized (and their FLOPs / bytes booked) for the frame capacity; the accounts report the real count
+    if (Fld > 0 && Fld != Fcount) {
+        const double r = (double)Fcount / (double)Fld;
+        flops_[2] *= r; flops_[3] *= r; bytes_[2] *= r; bytes_[3] *= r; mfma_flops_ *= r; mfma_exec_ *= r; bf16_exec_ *= r;
+    }
+    for (int st = 0; st < 4; st++) bytes_[st] += bytes_w_[st];
 
-    prof.frames = Ftot; prof.samples = Ntot; prof.phonemes = Ttot;
+    prof.frames = Fcount; prof.samples = Ntot; prof.phonemes = Ttot;
     prof.flops_text_encoder = flops_[0]; prof.flops_duration = flops_[1]; prof.flops_flow = flops_[2]; prof.flops_decoder = flops_[3];
     prof.flops_decoder_mfma = mfma_flops_; prof.decoder_mfma_launches = mfma_launches_; prof.bytes_decoder_min = bytes_[3] + 2.0 * (double)Ntot;
     prof.flops_decoder_mfma_executed = mfma_exec_; prof.flops_decoder_bf16_issued = bf16_exec_;
     prof.conv_math_fallbacks = h2_fallbacks; prof.conv_math_pinned = h2_disabled ? 1 : 0;
     prof.bytes_text_encoder = bytes_[0]; prof.bytes_duration = bytes_[1]; prof.bytes_flow = bytes_[2];
-    prof.ms_sync_wait_host = (float)sync_wait_ms_;
+    prof.ms_sync_wait_host = (float)sync_wait_ms_; prof.launch_ahead = ahead ? 1 : 0; prof.launch_ahead_misses = ahead_misses;
     if (profiling) {
         float t = 0;
         (void)hipEventElapsedTime(&t, ev_[0], ev_[1]); prof.ms_text_encoder = t;

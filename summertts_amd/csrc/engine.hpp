@@ -78,6 +78,9 @@ public:
     int h2_consecutive = 0; bool h2_disabled = false;   // two repeats in a row: the engine stays on split-bf16 until sts_set_conv_math
     double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
+    int launch_ahead = 1;              // 1: a one-utterance call enqueues flow + decoder before the frame count is on the host (sts_debug_set STS_DBG_LAUNCH_AHEAD)
+    long ahead_misses = 0;             // launch-ahead calls whose capacity was too small (repeated the waiting way)
+    std::vector<std::pair<int, long>> seen_tf_;    // (phonemes, most frames such an utterance produced on this engine): the launch-ahead capacity
     int flow_fused = 1;                // 1: the reverse flow as one launch per WaveNet layer where eligible (wn_flow.hip; two-term fp16 arithmetic only);
                                        // 0: one launch per conv (sts_debug_set STS_DBG_FLOW_FUSED)
 #ifdef STS_EXPERIMENTS                 // lab build only (`make exp`): the two persistent-kernel families that lost their A/B
@@ -103,7 +106,9 @@ private:
     int run_durations(RunCtx& c);
     int run_frame_workspace(RunCtx& c);
     int run_flow(RunCtx& c);
-    int run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0);
+    int run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wlen0);
+    int wait_frame_counts(RunCtx& c);
+    int frame_geometry(RunCtx& c);
     int run_output(RunCtx& c);
 #ifdef STS_EXPERIMENTS
     bool flow_program();            // builds (once) the op program of the persistent single-launch flow (persist.hip); false: not eligible
@@ -135,6 +140,7 @@ private:
     int cur_stage_ = 0;
     double flops_[4] = {0, 0, 0, 0};
     double bytes_[4] = {0, 0, 0, 0};
+    double bytes_w_[4] = {0, 0, 0, 0};       // the weight share of bytes_ (does not scale with the positions)
     double mfma_flops_ = 0, mfma_exec_ = 0, bf16_exec_ = 0, sync_wait_ms_ = 0; int mfma_launches_ = 0; bool in_mfma_region_ = false;
 };
 

@@ -297,7 +297,8 @@ void spline_step(const float* h, long ld, float filter_sqrt, const float* r0, co
 // counts by polling that word instead of a device-to-host copy + stream synchronisation.  arrive: a zeroed device counter.
 void durations(const float* r0, int sdp, float ea_m, float ea_logs, const float* ls, const int* forced,
                float* logw_out, int* dur, int* cum, int* frames, SegView seg, int B, hipStream_t st,
-               int* host_out = nullptr, long total = 0, int seq = 0, unsigned* arrive = nullptr);
+               int* host_out = nullptr, long total = 0, int seq = 0, unsigned* arrive = nullptr,
+               int* len_out = nullptr, int* win_len_out = nullptr, int cap = 0);     // optional: frames[b] clamped to cap, into two device tables
 // z[c][offF[b] + f] = m[c][offT[b] + phoneme(f)]
 void expand_frames(const float* m, long m_ld, const int* cum, SegView segT, SegView segF, int C,
                    float* z, long z_ld, int B, int max_frames, hipStream_t st);

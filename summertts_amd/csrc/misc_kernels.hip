@@ -584,7 +584,8 @@ constexpr int kMaxDur = 100000;   // sanity clamp per phoneme (the reference has
 __global__ __launch_bounds__(256) void durations_kernel(const float* r0, int sdp, float ea_m, float ea_logs,
                                                         const float* ls, const int* forced, float* logw_out,
                                                         int* dur, int* cum, int* frames, SegView seg,
-                                                        int* host_out, long total, int seq, unsigned* arrive, int B) {
+                                                        int* host_out, long total, int seq, unsigned* arrive, int B,
+                                                        int* len_out, int* win_len_out, int cap) {
     __shared__ int wsum[4];
     __shared__ int carry_s;
     const int b = blockIdx.x;
@@ -624,7 +625,13 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* r0, int sdp
         if (tid == 255) carry_s = pre + v;
         __syncthreads();
     }
-    if (tid == 0) frames[b] = carry_s < 1 ? 1 : carry_s;
+    if (tid == 0) {
+        const int f = carry_s < 1 ? 1 : carry_s;
+        frames[b] = f;
+        // a launch-ahead run: the kernels that follow read the utterance's length from these device words (never more than the
+        // capacity they were launched for -- the host repeats the run if the count was larger)
+        if (len_out) { const int fc = f < cap ? f : cap; len_out[b] = fc; win_len_out[b] = fc; }
+    }
     if (host_out) {
         // publish to the host: results first (system scope), then one arrival per workgroup; the last arriver writes the flag
         if (tid == 0) host_out[1 + total + b] = carry_s < 1 ? 1 : carry_s;
@@ -642,10 +649,10 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* r0, int sdp
 }
 void durations(const float* r0, int sdp, float ea_m, float ea_logs, const float* ls, const int* forced,
                float* logw_out, int* dur, int* cum, int* frames, SegView seg, int B, hipStream_t st,
-               int* host_out, long total, int seq, unsigned* arrive) {
+               int* host_out, long total, int seq, unsigned* arrive, int* len_out, int* win_len_out, int cap) {
     if (B <= 0) return;
     hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, st, r0, sdp, ea_m, ea_logs, ls, forced, logw_out, dur, cum, frames, seg,
-                       host_out, total, seq, arrive, B);
+                       host_out, total, seq, arrive, B, len_out, win_len_out, cap);
 }
 
 // length regulator: frame f of utterance b copies phoneme i with cum[i-1] <= f < cum[i]

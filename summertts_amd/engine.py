@@ -39,7 +39,7 @@ class Profile(C.Structure):
                 ("samples", C.c_int64), ("phonemes", C.c_int64), ("flops_decoder_mfma_executed", C.c_double),
                 ("bytes_text_encoder", C.c_double), ("bytes_duration", C.c_double), ("bytes_flow", C.c_double),
                 ("ms_sync_wait_host", C.c_float), ("flops_decoder_bf16_issued", C.c_double),
-                ("conv_math_fallbacks", C.c_int64), ("conv_math_pinned", C.c_int32), ("reserved0", C.c_int32)]
+                ("conv_math_fallbacks", C.c_int64), ("conv_math_pinned", C.c_int32), ("launch_ahead", C.c_int32), ("launch_ahead_misses", C.c_int64)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -221,7 +221,7 @@ class Synthesizer:
 
     def debug_set(self, key: str, value: int):
         """Test hooks (include/summertts_hip.h sts_debug_set): 'attn_block_min_wgs' | 'front_mode'."""
-        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "front_mode": 2, "pk_trace": 3, "trunk_mode": 4, "flow_fused": 5}[key], int(value)))
+        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "front_mode": 2, "pk_trace": 3, "trunk_mode": 4, "flow_fused": 5, "launch_ahead": 6}[key], int(value)))
 
     def set_profiling(self, on: bool):
         _check(self.lib, self.lib.sts_set_profiling(self.h, 1 if on else 0))

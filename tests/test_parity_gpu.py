@@ -961,6 +961,64 @@ def test_multi_device_rccl_gather_with_a_one_rank_communicator():
         assert np.array_equal(g, w)          # same shard, same engine path: the gather itself must not change a sample
 
 
+def test_launch_ahead_returns_the_samples_of_the_waiting_path():
+    """SURVEY 8 f3 / VERDICT r03 item 4: a one-utterance call no longer waits for the data-dependent frame count between the duration
+    predictor and the flow.  From the second call of an utterance length on, flow + decoder are enqueued for a predicted frame capacity
+    (the largest count this length has produced, in buckets of 64 frames) and read the real count from device memory; both paths size
+    buffers and dispatch by the bucket, so the samples are BIT-IDENTICAL to the waiting path's -- and both are pinned to the reference
+    (tests/golden/full_hifigan_sdp_T128.npz).  A count beyond the capacity (same length, longer durations) is detected, counted and
+    answered by repeating flow + decoder the waiting way."""
+    g, cfg, blob, utts, stride = load_golden_v2([p for p in golden_files_v2("full_") if p.endswith("full_hifigan_sdp_T128.npz")][0])
+    _, ids, sid_u, ls_u, dur_u, pcm_ref, wave_ref = utts[0]
+    syn = engine.Synthesizer(blob)
+    syn.set_profiling(True)
+    first = syn.infer_ids(ids, sid_u, ls_u)
+    p1 = syn.profile()
+    assert p1["launch_ahead"] == 0 and (syn.durations(len(ids)) == dur_u).all()
+    assert_pcm_close(first, pcm_ref, "waiting path vs the reference")
+    for _ in range(3):
+        again = syn.infer_ids(ids, sid_u, ls_u)
+        p2 = syn.profile()
+        assert p2["launch_ahead"] == 1 and p2["launch_ahead_misses"] == 0
+        assert p2["ms_sync_wait_host"] < 0.02, p2["ms_sync_wait_host"]        # (the count is read after the run's one stream synchronisation)
+        assert np.array_equal(again, first), "launch-ahead changed a sample"
+        assert (syn.durations(len(ids)) == dur_u).all()
+        assert abs(p2["flops_decoder_mfma"] - p1["flops_decoder_mfma"]) <= 1e-6 * p1["flops_decoder_mfma"]      # booked for the real count
+        assert p2["frames"] == p1["frames"] and p2["samples"] == first.size
+    syn.debug_set("launch_ahead", 0)
+    assert np.array_equal(syn.infer_ids(ids, sid_u, ls_u), first) and syn.profile()["launch_ahead"] == 0
+    syn.debug_set("launch_ahead", 1)
+    # the same length with longer durations: the capacity learnt above is too small
+    fresh = engine.Synthesizer(blob)
+    want_long = fresh.infer_ids(ids, sid_u, 1.3)
+    fresh.close()
+    got_long = syn.infer_ids(ids, sid_u, 1.3)
+    p3 = syn.profile()
+    assert p3["launch_ahead_misses"] == 1 and want_long.size > first.size
+    assert np.array_equal(got_long, want_long), "the repeated run differs from a waiting run"
+    # ... and back: now launched for the larger capacity (other dispatch decisions are possible: 1 LSB, not bit-identity)
+    back = syn.infer_ids(ids, sid_u, ls_u)
+    assert syn.profile()["launch_ahead"] == 1 and syn.profile()["launch_ahead_misses"] == 1
+    assert_pcm_close(back, pcm_ref, "launch-ahead with a larger capacity vs the reference")
+    syn.close()
+    # every decoder family / duration predictor, small models, against the oracle
+    for kind in ("mbb_fix", "ms_sdp", "istft_fix", "ms_hifigan_sdp", "odd"):
+        cfg = sb.tiny_cfg(kind)
+        blob = sb.make_blob(cfg, 31)
+        port = pyref.PortModel(blob)
+        syn = engine.Synthesizer(blob)
+        syn.set_profiling(True)
+        for T in (23, 9, 23, 23, 9):
+            ids = sb.synthetic_ids(T, cfg.vocab, salt=T)
+            sid = 1 if cfg.is_ms else 0
+            o = port.infer_ids(ids, sid, 1.1)
+            got = syn.infer_ids(ids, sid, 1.1)
+            assert (syn.durations(T) == o["durations"]).all()
+            assert_pcm_close(got, o["pcm"], f"{kind} T={T} (launch_ahead={syn.profile()['launch_ahead']})")
+        assert syn.profile()["launch_ahead"] == 1
+        syn.close()
+
+
 def test_multi_device_rccl_gather_with_three_emulated_ranks():
     """The N > 1 protocol of sts_multi's RCCL gather on a one-GPU box: THREE communicator ranks (device 0 listed three times) against
     tests/fake_rccl/libfake_rccl.so -- a host-side stand-in for the nine nccl* entry points multi.hip resolves, selected with
