@@ -75,6 +75,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef STS_H2_AR
 #define STS_H2_AR 2
 #endif
+// STS_GROUP_RPF (lab switch, default off): the grouped trunk launches request their residual tile before the K loop (236 registers instead of
+// 172, still two waves per SIMD).  Measured in round 4 (profiles/r04_ab_log.md): decoder 1.783-1.787 vs 1.765-1.772 ms at one utterance, a tie at
+// batch 32 -- the 64 early 16-byte loads sit in front of the first weight fragments (loads return in order) and cost the prologue what they
+// save the epilogue.
+#ifndef STS_GROUP_RPF
+#define STS_GROUP_RPF 0
+#endif
 #ifndef STS_H2_MINW
 #define STS_H2_MINW 1
 #endif
@@ -197,7 +204,7 @@ __device__ __forceinline__ void step_mfmas(f32x16 (&acc)[MW][NW], const u32x4 (&
 }
 
 
-template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1, bool NTL = false, int MATH = 0, bool NSUM = false>
+template <int MW, int NW, int WM, int WN, int NSUB = 1, int KG = 1, bool NTL = false, int MATH = 0, bool NSUM = false, bool RPF = false>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtiles, const int bx, const int by, const int b, const int pm = 0, [[maybe_unused]] const int tt_member = 0) {
     // pm (polyphase transposed convs): the workgroup's MT rows run over the MERGED row space phase * Cout_pad + row, so that
     // several phases (or all row blocks of a phase) share ONE staged, split input window instead of staging it once each
@@ -425,6 +432,12 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         }
         sj = nj; ssub = nsub; sc = nc;
     };
+    // RPF (grouped trunk launches): the residual of the output tile is requested before the K loop (see tile_res_prefetch)
+    f32x4u rpre[RPF ? MW : 1][RPF ? NW : 1][4];
+    const bool rpf = RPF && KG == 1 && a.epi == EPI_RESADD && a.out_stride == 1 && wvalid;
+    if constexpr (RPF) {
+        if (rpf) tile_res_prefetch<MW, NW, NTL>(a, rpre, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase);
+    }
     load_x(0);
     load_a(a_index(0, kg, 0), fa[0]);
     if constexpr (AR >= 3) load_a(1, fa[1]);
@@ -496,7 +509,11 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     }
     if ((STS_EXP & 32) && acc[0][0][0] != 12345.f) return;
     TT_STAMP(2);
-    if (wvalid) tile_epilogue<MW, NW, NTL>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
+    if constexpr (RPF) {
+        if (wvalid) tile_epilogue_pre<MW, NW, NTL>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b, rpre, rpf);
+    } else {
+        if (wvalid) tile_epilogue<MW, NW, NTL>(a, acc, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase, b);
+    }
 #ifdef STS_TILE_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores have left
     TT_STAMP(3);
@@ -522,7 +539,7 @@ __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_e
     if (interleave) { const int unit = t.bz * nx + t.bx; gi = unit % G.n; const int rest = unit / G.n; bx = rest % nx; b = rest / nx; }
     else { gi = t.bz / B; bx = t.bx; b = t.bz - gi * B; }
     const ConvArgs* ga = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    conv_bf3_body<MW, NW, WM, WN, NSUB, KG, false, MATH>(ga[gi], mtiles, bx, t.by, b, 0, gi);
+    conv_bf3_body<MW, NW, WM, WN, NSUB, KG, false, MATH, false, STS_GROUP_RPF && KG == 1 && MATH == 1>(ga[gi], mtiles, bx, t.by, b, 0, gi);
 }
 
 // tile codes: t = 0..5 below with 16-channel chunks, 8 + t the same tile with 32-channel chunks (NSUB = 2)

@@ -116,9 +116,43 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 16
 // bias load -- ~31 us of a 57 us tile for a 3-tap 128-channel conv.)
 // NTL: the residual is read with non-temporal loads (persistent stage kernel: it was written by another CU of this XCD inside
 // the same launch, a plain load could hit a stale line of this CU's vector L1)
+// The residual operand of the plain / residual epilogue below (EPI_RESADD, unit output stride), requested AHEAD of the K loop: the tile's
+// 16-byte residual loads then land under the MFMAs instead of costing the epilogue a memory round trip (round 4, tile trace: epilogue of a
+// 128 x 128 tile 7.5 us without a residual, 11.5 us with one).  Same addresses, same predicates as the epilogue's own loads.
 template <int MW, int NW, bool NTL = false>
-__device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[MW][NW], const int mbase, const int ncol0, const int l31,
-                                             const int half, const int n_count, const int out_len, const size_t out_base, const int phase, const int b) {
+__device__ __forceinline__ void tile_res_prefetch(const ConvArgs& a, f32x4u (&rv)[MW][NW][4], const int mbase, const int ncol0, const int l31,
+                                                 const int half, const int n_count, const int out_len, const size_t out_base, const int phase) {
+    const int out_off = a.out_off + phase;
+    const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
+#pragma unroll
+    for (int i = 0; i < MW; i++) {
+        const bool rows_ok = mbase + i * 32 < a.Cout_pad;
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const int n = ncol0 + q * 32 + m4;
+            const int pos = n + out_off;
+            const int klo = a.keep_hi > 0 ? a.keep_lo : 0, khi = a.keep_hi > 0 ? a.keep_hi : 0x7fffffff;
+            const bool full = n + 3 < n_count && pos >= 0 && pos + 3 < out_len && n >= klo && n + 3 < khi;
+            auto ok = [&](int e) { return n + e < n_count && pos + e >= 0 && pos + e < out_len && n + e >= klo && n + e < khi; };
+            const bool any = n < n_count && pos + 3 >= 0 && pos < out_len && n + 3 >= klo && n < khi;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int row = mbase + i * 32 + 8 * g + 4 * half + lane4;
+                rv[i][q][g] = f32x4u{0.f, 0.f, 0.f, 0.f};
+                if (rows_ok && row < a.Cout && any) {
+                    const float* rp = a.res + (size_t)row * a.res_ld + out_base + pos;
+                    if (full) rv[i][q][g] = NTL ? __builtin_nontemporal_load((const f32x4u*)rp) : *(const f32x4u*)rp;
+                    else { for (int e = 0; e < 4; e++) if (ok(e)) rv[i][q][g][e] = NTL ? __builtin_nontemporal_load(rp + e) : rp[e]; }
+                }
+            }
+        }
+    }
+}
+
+template <int MW, int NW, bool NTL, bool PRE, int PM, int PN>
+__device__ __forceinline__ void tile_epilogue_impl(const ConvArgs& a, f32x16 (&acc)[MW][NW], const int mbase, const int ncol0, const int l31,
+                                                  const int half, const int n_count, const int out_len, const size_t out_base, const int phase, const int b,
+                                                  const f32x4u (&pre)[PM][PN][4], const bool use_pre) {
     const int out_off = a.out_off + phase;
     if ((a.epi == EPI_STORE || a.epi == EPI_RESADD) && a.out_stride == 1) {
         // Plain convs (every ResBlock conv of the trunk).  Round 3 (tools/tile_trace.py): with one dword store and one dword residual
@@ -147,7 +181,15 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 auto ok = [&](int e) { return n + e < n_count && pos + e >= 0 && pos + e < out_len && n + e >= klo && n + e < khi; };
                 const bool any = n < n_count && pos + 3 >= 0 && pos < out_len && n + 3 >= klo && n < khi;
                 f32x4u rv[4];
-                if (a.epi == EPI_RESADD) {
+                bool have = false;
+                if constexpr (PRE) {
+                    if (a.epi == EPI_RESADD && use_pre) {
+                        have = true;
+#pragma unroll
+                        for (int g = 0; g < 4; g++) rv[g] = pre[i][q][g];
+                    }
+                }
+                if (a.epi == EPI_RESADD && !have) {
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         rv[g] = f32x4u{0.f, 0.f, 0.f, 0.f};
@@ -312,6 +354,20 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             }
         });
     });
+}
+
+template <int MW, int NW, bool NTL = false>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x16 (&acc)[MW][NW], const int mbase, const int ncol0, const int l31,
+                                             const int half, const int n_count, const int out_len, const size_t out_base, const int phase, const int b) {
+    const f32x4u none[1][1][4] = {};
+    tile_epilogue_impl<MW, NW, NTL, false, 1, 1>(a, acc, mbase, ncol0, l31, half, n_count, out_len, out_base, phase, b, none, false);
+}
+// ... with the residual tile already in registers (tile_res_prefetch) when use_pre
+template <int MW, int NW, bool NTL = false>
+__device__ __forceinline__ void tile_epilogue_pre(const ConvArgs& a, f32x16 (&acc)[MW][NW], const int mbase, const int ncol0, const int l31,
+                                                 const int half, const int n_count, const int out_len, const size_t out_base, const int phase, const int b,
+                                                 const f32x4u (&pre)[MW][NW][4], const bool use_pre) {
+    tile_epilogue_impl<MW, NW, NTL, true, MW, NW>(a, acc, mbase, ncol0, l31, half, n_count, out_len, out_base, phase, b, pre, use_pre);
 }
 
 }  // namespace sts

@@ -12,9 +12,9 @@
   profiles/latest_pmc.json          {"by_workload": {<key>: summary}} -- bench.py attaches a summary to its `roofline` object only
                                     when the workload key AND the kernel build id (sha256 of summertts_amd/csrc) match.
 
-Kernel classes are found by DISPATCH ORDER inside a step: the `--flow-launches` convs after a step's
-expand_frames_kernel are the reverse flow, the next launch is conv_pre, and everything up to the step's last sum_scale_kernel
-(sum_scale itself excluded) is the decoder trunk -- the upsamplers and the grouped / fused ResBlock layers, whichever kernel
+Kernel classes are found by DISPATCH ORDER inside a step: the flow_layer / flow_finish launches (round 4; before: the
+`--flow-launches` convs) after a step's expand_frames_kernel are the reverse flow, the next launch is conv_pre, and everything up to
+the step's last ResBlock-layer launch (sum_scale launches excluded) is the decoder trunk -- the upsamplers and the grouped / fused ResBlock layers, whichever kernel
 variant the dispatcher picked for them.
 
 FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half the bytes of wide
@@ -63,17 +63,25 @@ def classify(names, flow_launches):
     starts = [i for i, n in enumerate(names) if "expand_frames_kernel" in n] + [len(names)]
     for s, e in zip(starts[:-1], starts[1:]):
         i = s + 1
-        nconv = 0
-        while i < e and nconv < flow_launches:
-            if "conv_" in names[i]:
+        if any("flow_layer_kernel" in names[k] for k in range(s + 1, e)):
+            # round 4: the reverse flow = one launch per WaveNet layer (wn_flow.hip) + the finishing kernel
+            while i < e and ("flow_layer_kernel" in names[i] or "flow_finish_kernel" in names[i] or "conv_" in names[i] and "flow_layer_kernel" in " ".join(names[i:i + 3])):
                 lab[i] = "flow"
-                nconv += 1
-            i += 1
+                i += 1
+        else:
+            nconv = 0
+            while i < e and nconv < flow_launches:
+                if "conv_" in names[i]:
+                    lab[i] = "flow"
+                    nconv += 1
+                i += 1
         pre = i                                              # conv_pre
-        sums = [k for k in range(pre, e) if "sum_scale_kernel" in names[k]]
-        if not sums:
+        # the trunk ends with the last ResBlock layer launch of the step (fused layer / grouped conv) -- or the sum_scale behind it where
+        # the chain mean is still a launch of its own; conv_post and the tail follow
+        ends = [k for k in range(pre, e) if "resblock_" in names[k] or "_group_kernel" in names[k] or "sum_scale_kernel" in names[k]]
+        if not ends:
             continue
-        for k in range(pre + 1, sums[-1]):
+        for k in range(pre + 1, ends[-1] + 1):
             if "sum_scale_kernel" not in names[k] and "rocclr" not in names[k]:
                 lab[k] = "trunk"
     return lab
