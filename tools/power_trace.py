@@ -23,13 +23,54 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def find_sensors():
+def all_sensors():
+    out = []
     for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
         p = next((os.path.join(hw, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, n))), None)
         f = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
         if p:
-            return p, f
-    return None, None
+            out.append((p, f))
+    return out
+
+
+def find_sensors():
+    c = all_sensors()
+    return c[0] if c else (None, None)
+
+
+def pick_loaded_sensor(load_fn):
+    """A box may expose the hwmon nodes of several cards while HIP sees one GPU: the sensor that belongs to OUR device is the one whose
+    power rises while `load_fn` keeps the device busy (round 4: a box whose card0 was somebody else's idle GPU reported 250 W / 95 MHz
+    through a whole trace)."""
+    cands = all_sensors()
+    if len(cands) <= 1:
+        return cands[0] if cands else (None, None)
+
+    def rd(pf):
+        try:
+            return int(open(pf).read()) / 1e6
+        except Exception:
+            return float("nan")
+    idle = [rd(pf) for pf, _ in cands]
+    peak = list(idle)
+    stop = [False]
+
+    def poll():
+        while not stop[0]:
+            for i, (pf, _) in enumerate(cands):
+                v = rd(pf)
+                if v == v and (peak[i] != peak[i] or v > peak[i]):
+                    peak[i] = v
+            time.sleep(0.02)
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    load_fn(1.5)
+    stop[0] = True
+    th.join()
+    rise = [(peak[i] - idle[i]) if (peak[i] == peak[i] and idle[i] == idle[i]) else -1.0 for i in range(len(cands))]
+    best = int(np.argmax(rise))
+    print("sensor candidates (idle W -> peak W under load): " + ", ".join(f"{os.path.basename(os.path.dirname(os.path.dirname(pf)))}/{os.path.basename(os.path.dirname(pf))} {idle[i]:.0f}->{peak[i]:.0f}" for i, (pf, _) in enumerate(cands)) + f"; using #{best}", flush=True)
+    return cands[best]
 
 
 class Sampler:
@@ -97,6 +138,15 @@ def main():
         time.sleep(sec)
         return ""
 
+    def calib_load(sec):                 # keeps OUR device busy: which hwmon node reacts?
+        ids0 = [sb.synthetic_ids(128, cfg.vocab, salt=0)] * 8
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < sec:
+            syn.run_batch(ids0)
+    if s.mode == "sysfs":
+        s.pfile, s.ffile = pick_loaded_sensor(calib_load)
+        print(f"sensors in use: power={s.pfile} sclk={s.ffile}", flush=True)
+
     def synth(batch):
         lens = [128] if batch == 1 else np.random.default_rng(1234).integers(64, 257, size=batch).tolist()
         ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=u) for u, t in enumerate(lens)]
@@ -138,11 +188,13 @@ def main():
         s.phase("idle", idle, 1.0)
         s.phase("synthesis step, batch 1 (128 phonemes), default arithmetic", synth(1), secs)
         s.phase("synthesis step, batch 8 (64..256 phonemes), default arithmetic", synth(8), secs)
+        s.phase("synthesis step, batch 32 (config 2), default arithmetic", synth(32), secs)
         s.phase("bare fp16 MFMA loop, two-term planes of random fp32", ubh(2), secs)
         return
     s.phase("idle", idle, 2.0)
     s.phase("synthesis step, batch 1 (128 phonemes)", synth(1), secs)
     s.phase("synthesis step, batch 8 (64..256 phonemes)", synth(8), secs)
+    s.phase("synthesis step, batch 32 (config 2)", synth(32), secs)
     s.phase("bare MFMA loop, constant operands", ub(0), secs)
     s.phase("bare MFMA loop, random bf16 operands", ub(1), secs)
     s.phase("bare MFMA loop, hi/mid/lo planes of random fp32", ub(2), secs)
