@@ -25,7 +25,8 @@
 //     activation, splits, and writes three 16-byte vectors.  The split costs ~7 VALU ops per staged element and is
 //     amortised over all output rows and taps that read it;
 //   * a wave owns a (32 MW) x (32 NW) output tile: every A fragment is reused over NW column tiles and every B fragment
-//     over MW row tiles, 6 MW NW MFMAs per (chunk, tap) step, accumulators interleaved so no MFMA waits for its predecessor.#pragma once
+//     over MW row tiles, 6 MW NW MFMAs per (chunk, tap) step, accumulators interleaved so no MFMA waits for its predecessor.
+#pragma once
 #include "kernels.hpp"
 #include "devmath.hpp"
 #include "conv_common.hpp"

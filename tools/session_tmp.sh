@@ -1,4 +1,17 @@
-mkdir -p gpurun_out/s14
-ls /sys/class/drm/ | head -30 > gpurun_out/s14/drm.txt
-POWER_TRACE_SHORT=1 timeout 200 python tools/power_trace.py 5 > gpurun_out/s14/power_trace.log 2>&1
-cat gpurun_out/s14/power_trace.log
+mkdir -p gpurun_out/s16
+timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "full_size_configs or near_full_scale or tiny or duration or text_encoder" 2>&1 | tail -5 > gpurun_out/s16/pytest.txt
+cat gpurun_out/s16/pytest.txt
+B="python bench.py --no-cpu-baseline --no-f32-leg --pipeline-engines 0 --min-seconds 0"
+for i in 1 2; do
+$B --steps 40 --warmup 5 > gpurun_out/s16/on_$i.json 2> gpurun_out/s16/e1
+$B --steps 40 --warmup 5 --debug-set ffn_fused=0 > gpurun_out/s16/off_$i.json 2> gpurun_out/s16/e2
+done
+tail -3 gpurun_out/s16/e1
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/s16/*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); st=d.get('stages_ms') or d.get('stages') or {}
+        print(f, d['ms_per_step'], {k:round(v,3) for k,v in st.items()} if isinstance(st,dict) else st)
+    except Exception as e: print(f, 'ERR', e)
+PY
