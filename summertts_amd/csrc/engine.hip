@@ -582,7 +582,7 @@ int Engine::run_text_encoder(RunCtx& c) {
         memset(&at, 0, sizeof(at));
         at.q = bt.qkv; at.k = bt.qkv + (size_t)H * Ttot; at.v = bt.qkv + (size_t)2 * H * Ttot; at.o = bt.att; at.ld = Ttot;
         at.relk = a.relk; at.relv = a.relv; at.kc = a.kc; at.px = a.px; at.win = a.win; at.nheads = 2;
-        at.seg = lvT.seg; at.B = B; at.max_len = maxT; at.block_min_wgs = attn_block_min_wgs;
+        at.seg = lvT.seg; at.B = B; at.max_len = maxT; at.block_min_wgs = attn_block_min_wgs; at.attn_reg = attn_reg;
         attention(at, stream);
         flops_[0] += 2.0 * 2.0 * (double)a.ch * (double)maxT * (double)Ttot;   // ~ QK^T + PV
         bytes_[0] += 4.0 * 4.0 * (double)H * (double)Ttot;                       // q, k, v in; o out

@@ -77,6 +77,7 @@ public:
     long h2_fallbacks = 0;             // runs repeated in split-bf16 because an activation left fp16's range (conv_math 3)
     int h2_consecutive = 0; bool h2_disabled = false;   // two repeats in a row: the engine stays on split-bf16 until sts_set_conv_math
     double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
+    int attn_reg = 1;                  // 1: one-query attention with its operands in registers (attention_reg_kernel) where the shape allows (STS_DBG_ATTN_REG)
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
     int launch_ahead = 1;              // 1: a one-utterance call enqueues flow + decoder before the frame count is on the host (sts_debug_set STS_DBG_LAUNCH_AHEAD)
     long ahead_misses = 0;             // launch-ahead calls whose capacity was too small (repeated the waiting way)

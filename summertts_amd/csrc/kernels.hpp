@@ -144,6 +144,7 @@ struct AttnArgs {
     int kc, px, win, nheads;
     SegView seg; int B, max_len;
     int block_min_wgs;              // the 16-queries-per-workgroup matrix-core kernel from this many workgroups on (0: default 96)
+    int attn_reg;                   // 1: the one-query kernel with its operands in registers where the shape allows (attention_reg_kernel)
 };
 
 #ifdef STS_EXPERIMENTS   // lab build only (`make exp`): persistent-kernel families that lost their A/B against the launch path

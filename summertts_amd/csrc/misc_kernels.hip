@@ -230,6 +230,155 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 }
 // ---------------------------------------------------------------------------------------------
+// The one-query-per-workgroup attention with every global operand requested before the first dependent step (round 4).
+// attention_kernel above walks a chain of dependent trips to L2 (q -> relK -> K -> ... -> V -> relV: ~16.8 us per launch at one
+// 128-phoneme utterance, profiles/r04_c1_timeline.txt); here a wave requests its quarter of the channels of K AND V for all keys
+// (2 x 24 x JPL registers per lane, lanes along the keys: 256-byte segments), its quarter of relK and the output stage's relV
+// right after the query -- which one lane per channel loads and v_readlane hands to the wave as scalars, so no barrier (and no
+// LDS round trip) separates it from the score product.  The scores are formed as above (four running sums over channels c % 4 per wave, partials
+// added as (0 + 1) + (2 + 3): bit-identical when kc is a multiple of 16); P.V is summed per lane over its JPL keys, the 64 lane partials of a channel meet through LDS.
+//   T <= 64 JPL keys, kc <= 96, px <= 16 (attention() falls back to the kernel above otherwise).
+constexpr int ATR_CW = 24;      // channels per wave
+constexpr int ATR_LD = 65;      // lane stride of the partial-output buffer (odd: conflict-free in both directions)
+
+template <int JPL>
+__global__ __launch_bounds__(256) void attention_reg_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TMAX = 64 * JPL;
+    const int b = blockIdx.z, h = blockIdx.y, i = blockIdx.x;
+    const int T = seg_len(a.seg, b);
+    if (i >= T) return;
+    const size_t base = (size_t)seg_start(a.seg, b);
+    const int kc = a.kc, px = a.px, win = a.win, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* red = sm;                      // [8]
+    float* P = sm + 8;                    // [TMAX]
+    float* part = P + TMAX;               // [4][TMAX] partial scores
+    float* qr = part + 4 * TMAX;          // [4][32] partial relative-key logits
+    float* buf = qr + 128;                // [4 * ATR_CW][ATR_LD] per-lane partial outputs
+    const int cw = (kc + 3) / 4, c0 = wave * cw, nc = (c0 + cw < kc ? c0 + cw : kc) - c0;   // wave w owns channels [c0, c0 + nc)
+    const float sq = sqrtf((float)kc);
+
+    // ---- 1. every global operand, in the order of use.  Addresses are clamped into the tensors and the values masked afterwards:
+    // no branch (and so no wait) sits between two requests
+    float qv[ATR_CW], kv[ATR_CW][JPL], rk[ATR_CW], vv[ATR_CW][JPL], rv[16];
+    int jc[JPL];
+#pragma unroll
+    for (int jj = 0; jj < JPL; jj++) jc[jj] = lane + 64 * jj < T ? lane + 64 * jj : T - 1;
+    const int occ = tid >> 1, ohf = tid & 1;     // output stage: thread (channel, half of the lanes)
+    const int occ_c = occ < kc ? occ : kc - 1, lane_px = lane < px ? lane : px - 1;
+    // the query: lane c holds channel c0 + c; v_readlane hands the values to all lanes below (no LDS round trip, no barrier)
+    const int qch = c0 + lane < kc ? c0 + lane : kc - 1;
+    const float qlane = a.q[(size_t)(h * kc + qch) * a.ld + base + i];
+#pragma unroll
+    for (int c = 0; c < ATR_CW; c++) {
+        const int ch = c0 + c < kc ? c0 + c : kc - 1;
+#pragma unroll
+        for (int jj = 0; jj < JPL; jj++) kv[c][jj] = a.k[(size_t)(h * kc + ch) * a.ld + base + jc[jj]];
+    }
+    if (win > 0) {
+#pragma unroll
+        for (int c = 0; c < ATR_CW; c++) {
+            const int ch = c0 + c < kc ? c0 + c : kc - 1;
+            rk[c] = a.relk[(size_t)ch * px + lane_px];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < ATR_CW; c++) {
+        const int ch = c0 + c < kc ? c0 + c : kc - 1;
+#pragma unroll
+        for (int jj = 0; jj < JPL; jj++) vv[c][jj] = a.v[(size_t)(h * kc + ch) * a.ld + base + jc[jj]];
+    }
+    if (win > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) rv[r] = a.relv[(size_t)occ_c * px + (r < px ? r : px - 1)];
+    }
+    const float qscaled = qlane / sq;
+#pragma unroll
+    for (int c = 0; c < ATR_CW; c++) {
+        const bool live = c < nc;
+        qv[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qscaled), c));   // (past nc: a finite value against zeroed k / relK)
+        rk[c] = (live && win > 0) ? rk[c] : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JPL; jj++) {
+            const bool ok = live && lane + 64 * jj < T;
+            kv[c][jj] = ok ? kv[c][jj] : 0.f;
+            vv[c][jj] = ok ? vv[c][jj] : 0.f;
+        }
+    }
+
+    // ---- 2. partial scores and partial relative-key logits of the wave's channels
+#pragma unroll
+    for (int jj = 0; jj < JPL; jj++) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < ATR_CW; c += 4) {
+            s0 += qv[c] * kv[c][jj]; s1 += qv[c + 1] * kv[c + 1][jj]; s2 += qv[c + 2] * kv[c + 2][jj]; s3 += qv[c + 3] * kv[c + 3][jj];   // (channels past nc: 0 * 0)
+        }
+        part[wave * TMAX + lane + 64 * jj] = (s0 + s1) + (s2 + s3);
+    }
+    if (win > 0 && lane < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < ATR_CW; c++) s += qv[c] * rk[c];
+        qr[wave * 32 + lane] = s;
+    }
+    __syncthreads();
+
+    // ---- 3. softmax without a max shift (nn_softmax.cpp:5-28), one key per thread
+    float e = 0.f;
+    if (tid < T) {
+        float sc = (part[tid] + part[TMAX + tid]) + (part[2 * TMAX + tid] + part[3 * TMAX + tid]);
+        const int r = tid - i + win;
+        if (win > 0 && r >= 0 && r < px) sc += (qr[r] + qr[32 + r]) + (qr[64 + r] + qr[96 + r]);
+        e = expf(sc);
+    }
+    const float ws = wave_sum(e);
+    if (lane == 0) red[wave] = ws;
+    __syncthreads();
+    const float sum = red[0] + red[1] + red[2] + red[3];
+    if (tid < TMAX) P[tid] = tid < T ? e / sum : 0.f;
+    __syncthreads();
+
+    // ---- 4. P.V over the lane's keys
+    float pj[JPL];
+#pragma unroll
+    for (int jj = 0; jj < JPL; jj++) pj[jj] = P[lane + 64 * jj];
+#pragma unroll
+    for (int c = 0; c < ATR_CW; c++) {
+        float o = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JPL; jj++) o += pj[jj] * vv[c][jj];
+        buf[(wave * ATR_CW + c) * ATR_LD + lane] = o;            // (rows past nc: zeros nobody reads)
+    }
+    __syncthreads();
+
+    // ---- 5. the 64 lane partials of a channel: two threads x 32, then the banded relative-value term
+    if (occ < kc) {
+        const int wv = occ / cw, cl = occ - wv * cw;
+        const float* p = buf + (wv * ATR_CW + cl) * ATR_LD + ohf * 32;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 32; m += 4) { o0 += p[m]; o1 += p[m + 1]; o2 += p[m + 2]; o3 += p[m + 3]; }
+        float o = (o0 + o1) + (o2 + o3);
+        o += __shfl_xor(o, 1, 64);
+        if (ohf == 0) {
+            float orel = 0.f;
+            if (win > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {           // branch-free: absent terms add P * 0
+                    const int jj = i + r - win;
+                    const bool ok = r < px && jj >= 0 && jj < T;
+                    orel += P[ok ? jj : 0] * (ok ? rv[r] : 0.f);
+                }
+            }
+            a.o[(size_t)(h * kc + occ) * a.ld + base + i] = o + orel;
+        }
+    }
+}
+static size_t attention_reg_lds(int jpl) { return (size_t)(8 + 5 * 64 * jpl + 128 + 4 * ATR_CW * ATR_LD) * sizeof(float); }
+
+// ---------------------------------------------------------------------------------------------
 // The same attention on the matrix cores, 16 queries per workgroup (round 2).  The kernel above re-reads an utterance's
 // K and V once per query (2 x kc x T floats per workgroup): fine for one short utterance, but 46 % of the text encoder's
 // time at batch 8 (profiles/r02_b8_kernel_stats.csv: 98 us per launch).  Here a workgroup (4 waves) owns a block of 16
@@ -419,6 +568,11 @@ void attention(const AttnArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(attention_mfma_kernel, dim3((a.max_len + 15) / 16, a.nheads, a.B), dim3(256), lds, st, a, Tpad);
             return;
         }
+    }
+    if (a.attn_reg && a.kc <= 4 * ATR_CW && a.px <= 16 && a.max_len <= 256) {   // operands in registers (round 4)
+        if (a.max_len <= 128) hipLaunchKernelGGL(attention_reg_kernel<2>, dim3(a.max_len, a.nheads, a.B), dim3(256), attention_reg_lds(2), st, a);
+        else hipLaunchKernelGGL(attention_reg_kernel<4>, dim3(a.max_len, a.nheads, a.B), dim3(256), attention_reg_lds(4), st, a);
+        return;
     }
     size_t lds = (size_t)(a.kc + 8 + (a.px > 16 ? a.px : 16) + 5 * (size_t)a.max_len) * sizeof(float);
     if (lds > 48 * 1024)
