@@ -91,6 +91,10 @@ int sts_run_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int
 int sts_set_host_pcm(sts_engine* e, int enable);
 int sts_copy_pcm_device(sts_engine* e, void* device_dst, int64_t capacity_samples);
 int sts_copy_pcm_host(sts_engine* e, int16_t* host_dst, int64_t capacity_samples);
+/* Zero-copy form of sts_copy_pcm_host for a caller that consumes the PCM before its next call on this engine: *pcm points into
+ * the engine-owned pinned host buffer the last run downloaded into (needs sts_set_host_pcm(e, 1); STS_ESTATE otherwise), *count =
+ * samples of all utterances back to back.  The pointer is valid until the next run / destroy on this engine. */
+int sts_pcm_host_view(sts_engine* e, const int16_t** pcm, int64_t* count);
 
 /* Parity/diagnostic controls (test infrastructure hooks; defaults reproduce the reference):
  *   forced durations: per-phoneme frame counts that override ceil(exp(logw)*lengthScale) for the NEXT
@@ -156,13 +160,16 @@ typedef struct sts_profile {
     int32_t conv_math_pinned;             /* 1: after two such calls in a row the engine now stays in the split-bf16 form (until sts_set_conv_math) */
     int32_t launch_ahead;                 /* 1: this run enqueued flow + decoder before the frame count reached the host (one utterance; ms_sync_wait_host ~ 0) */
     int64_t launch_ahead_misses;          /* launch-ahead runs of this engine so far whose predicted frame capacity was too small (flow + decoder repeated) */
+    float us_host_setup;                  /* host time from the entry of the run to the first launch being enqueued (input checks, tables, the one upload) */
+    float us_host_enqueue;                /* host time from the entry of the run to the last launch being enqueued (the GPU runs behind it) */
+    float us_host_tail;                   /* host time from the return of the run's last stream synchronisation to the return of the call */
 } sts_profile;
 int sts_set_profiling(sts_engine* e, int enable);
 /* The struct only ever grows at its end (STS_ABI_VERSION counts the revisions).  sts_get_profile_ex copies min(size_bytes,
  * sizeof(sts_profile)) bytes, so a client compiled against an older header passes ITS sizeof and is never overrun;
  * sts_get_profile(e, p) == sts_get_profile_ex(e, p, sizeof(sts_profile)) of the header this library was built from -- use it only
  * when client and library are built together. */
-#define STS_ABI_VERSION 5
+#define STS_ABI_VERSION 6
 int sts_abi_version(void);
 /* bit 0: lab build (-DSTS_EXPERIMENTS: environment knobs of knobs.hpp, the persistent-kernel families, every conv tile code);
  * 0 for the shipped library */

@@ -77,6 +77,13 @@ int sts_copy_pcm_host(sts_engine* e, int16_t* dst, int64_t cap) {
     return STS_OK;
 }
 
+int sts_pcm_host_view(sts_engine* e, const int16_t** pcm, int64_t* count) {
+    if (!e || !pcm || !count) return set_err(STS_EINVAL, "null argument");
+    if (!e->eng.h_pcm || !e->eng.d_pcm) return set_err(STS_ESTATE, "no host copy of the PCM (sts_set_host_pcm(e, 1) before the run)");
+    *pcm = e->eng.h_pcm; *count = e->eng.total_samples;
+    return STS_OK;
+}
+
 int sts_infer_ids_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int32_t* n, const int32_t* sid,
                         const float* length_scale, int16_t** pcm_out, int32_t* n_out) {
     if (!pcm_out || !n_out) return set_err(STS_EINVAL, "null output");

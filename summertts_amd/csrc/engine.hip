@@ -113,6 +113,7 @@ bool Engine::ensure_pinned(size_t bytes) {
 }
 
 void Engine::stage_begin(int s) { cur_stage_ = s; }
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); }
 
 // builds the kernel arguments of one conv and books its FLOPs / minimum HBM bytes
@@ -1498,11 +1499,13 @@ int Engine::run_once(int B, const int32_t* const* ids, const int32_t* n, const i
     ps_tab_busy_ = false;          // (the previous run ended with a stream synchronisation)
 #endif
 
+    host_t0_ = now_us(); host_t_sync_ = 0;
     RunCtx c;
     c.B = B; c.ids = ids; c.n = n; c.sid = sid; c.ls = ls; c.ss = ss;
     int rc;
     if ((rc = run_setup(c)) != STS_OK) return rc;
     mark(0);
+    host_us_setup_ = (float)(now_us() - host_t0_); host_us_enq_ = 0;
     if ((rc = run_text_encoder(c)) != STS_OK) return rc;
     if ((rc = run_durations(c)) != STS_OK) return rc;
     if ((rc = run_frame_workspace(c)) != STS_OK) return rc;
@@ -1522,7 +1525,9 @@ int Engine::run_output(RunCtx& c) {
             // everything is enqueued.  The PCM download is queued for the CAPACITY (<= 63 frames more than needed) and the run's one
             // stream synchronisation happens before the count is looked at: the host never waits for the count by itself
             if (host_pcm) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)Fld * hop * 2, hipMemcpyDeviceToHost, stream));
+            host_us_enq_ = (float)(now_us() - host_t0_);
             HIPCK(hipStreamSynchronize(stream));
+            host_t_sync_ = now_us();
             if ((rc = wait_frame_counts(c)) != STS_OK) return rc;
             if (c.Ftot > Fld) {
                 // more frames than the capacity this call was launched for (an utterance of this length had never needed as many): the
@@ -1548,7 +1553,11 @@ int Engine::run_output(RunCtx& c) {
             if (!ahead) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)total_samples * 2, hipMemcpyDeviceToHost, stream));
             h_pcm = (const int16_t*)pinned_pcm_;
         }
-        if (!ahead) HIPCK(hipStreamSynchronize(stream));
+        if (!ahead) {
+            host_us_enq_ = (float)(now_us() - host_t0_);
+            HIPCK(hipStreamSynchronize(stream));
+            host_t_sync_ = now_us();
+        }
         HIPCK(hipGetLastError());
     } else {
         // Streaming: chunk c = frames [f0, f1) is decoded from the window [f0 - halo, f1 + halo)
@@ -1609,6 +1618,8 @@ int Engine::run_output(RunCtx& c) {
         (void)hipEventElapsedTime(&t, ev_[5], ev_[6]); prof.ms_decoder_mfma = t;
         prof.ms_total_device = prof.ms_text_encoder + prof.ms_duration + prof.ms_flow + prof.ms_decoder;
     }
+    prof.us_host_setup = host_us_setup_; prof.us_host_enqueue = host_us_enq_;
+    prof.us_host_tail = host_t_sync_ > 0 ? (float)(now_us() - host_t_sync_) : 0.f;
     return STS_OK;
 }
 

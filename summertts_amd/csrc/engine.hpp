@@ -64,6 +64,8 @@ public:
     std::vector<int32_t> n_samples;    // per utterance
     int64_t total_samples = 0;
     int16_t* d_pcm = nullptr;          // device, packed
+    float host_us_setup_ = 0, host_us_enq_ = 0;
+    double host_t0_ = 0, host_t_sync_ = 0;   // steady-clock microseconds: entry of the run, return of its last stream synchronisation
     const int16_t* h_pcm = nullptr;    // host copy of the last run's PCM (pinned, engine-owned) when host_pcm is set, else null
     bool host_pcm = false;             // download the PCM as part of run(): one stream sync per call instead of two
     std::vector<int32_t> durations_h;  // packed

@@ -961,6 +961,33 @@ def test_multi_device_rccl_gather_with_a_one_rank_communicator():
         assert np.array_equal(g, w)          # same shard, same engine path: the gather itself must not change a sample
 
 
+def test_prepared_batch_and_host_view_return_the_copied_samples():
+    """The bench step's host path (bench.py step()): run_batch on a PreparedBatch (argument arrays built once) and the zero-copy view of
+    the engine's pinned download buffer (sts_pcm_host_view) must hand over exactly the samples of the copying calls, run after run, and
+    the view must refuse to exist when the run did not download (sts_set_host_pcm(0))."""
+    g, cfg, blob, utts, stride = load_golden_v2([p for p in golden_files_v2("amp_") if p.endswith("amp_hifigan_fix_sat10.npz")][0])
+    syn = engine.Synthesizer(blob)
+    utts = [utts[0], utts[0]]                # the same utterance twice: a batch
+    ids = [u[1] for u in utts]
+    sid = [u[2] for u in utts]
+    ls = [u[3] for u in utts]
+    want = syn.infer_batch(ids, sid, ls)
+    prep = syn.prepare(ids, sid, ls)
+    for _ in range(3):
+        n_out = syn.run_batch(prep)
+        view = syn.pcm_host(copy=False)
+        assert not view.flags.writeable and view.size == int(n_out.sum())
+        assert np.array_equal(view, np.concatenate(want)) and np.array_equal(syn.pcm_host(), view)
+    p = syn.profile()
+    assert p["us_host_setup"] > 0 and p["us_host_enqueue"] >= p["us_host_setup"] and p["us_host_tail"] >= 0
+    syn.set_host_pcm(False)
+    syn.run_batch(prep)
+    with pytest.raises(engine.StsError):
+        syn.pcm_host(copy=False)
+    assert np.array_equal(syn.pcm_host(), np.concatenate(want))          # (the copying call downloads by itself)
+    syn.close()
+
+
 def test_launch_ahead_returns_the_samples_of_the_waiting_path():
     """SURVEY 8 f3 / VERDICT r03 item 4: a one-utterance call no longer waits for the data-dependent frame count between the duration
     predictor and the flow.  From the second call of an utterance length on, flow + decoder are enqueued for a predicted frame capacity
