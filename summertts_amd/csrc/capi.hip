@@ -160,6 +160,7 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_FLOW_FUSED: e->eng.flow_fused = value != 0; return STS_OK;
         case STS_DBG_LAUNCH_AHEAD: e->eng.launch_ahead = value != 0; return STS_OK;
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
+        case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
 #ifdef STS_EXPERIMENTS
         case STS_DBG_FRONT_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "front mode must be 0, 1 or 2"); e->eng.front_mode = value; return STS_OK;
         case STS_DBG_TRUNK_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "trunk mode must be 0, 1 or 2"); e->eng.trunk_mode = value; return STS_OK;

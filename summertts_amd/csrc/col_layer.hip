@@ -30,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int cl_seg_start(const SegView& s, int b) { return (s.off ? s.off[b] : s.ioff) * s.scale + b * s.extra; }
 __device__ __forceinline__ int cl_seg_len(const SegView& s, int b) { return (s.off ? s.len[b] : s.ilen) * s.scale + s.extra; }
 
-template <int NSUB>
+template <int NSUB, bool TAIL = false>   // TAIL: the ConvFlow projection + spline step behind the layer (ColLayerArgs::tp_*)
 __global__ __launch_bounds__(64 * NSUB) void col_layer_kernel(ColLayerArgs a) {
     constexpr int C = 16 * NSUB, KQ = C / 4, CG = 4 * NSUB;     // k-steps of 4 channels; channel groups of the input stage
     constexpr int KH = KQ > 48 ? KQ / 2 : KQ;                   // B values kept in registers at a time
@@ -102,6 +102,16 @@ __global__ __launch_bounds__(64 * NSUB) void col_layer_kernel(ColLayerArgs a) {
         }
     }
 
+    // tail operands (the 29-row projection [C][32]: 8 floats per thread; the latent halves of the 16 time steps)
+    f32x4 tw0 = {0.f, 0.f, 0.f, 0.f}, tw1 = {0.f, 0.f, 0.f, 0.f};
+    float t_in = 0.f, t_keep = 0.f, t_bias = 0.f;
+    if constexpr (TAIL) {
+        const f32x4* twp = reinterpret_cast<const f32x4*>(a.tp_w) + tid;
+        tw0 = twp[0]; tw1 = twp[64 * NSUB];
+        if (tid < 32) t_bias = tid < 29 ? a.tp_b[tid] : 0.f;
+        if (tid < 16 && live) { t_in = a.tp_r1 ? a.tp_r1[base + pos] : 0.f; t_keep = a.tp_r0 ? a.tp_r0[base + pos] : 0.f; }   // null = the all-zero latent (noise scale 0)
+    }
+
     // ---- 2. input stage
     if (a.dw_w) {
         float v[4];
@@ -165,16 +175,44 @@ __global__ __launch_bounds__(64 * NSUB) void col_layer_kernel(ColLayerArgs a) {
     s = 0.f; sq = 0.f;
 #pragma unroll
     for (int k = 0; k < NSUB; k++) { s += red[0][k][col]; sq += red[1][k][col]; }
-    if (!live) return;
+    if (!live && !TAIL) return;
     const float mean = s / (float)C;
     const float var = sq * (float)(1. / (float)C) - mean * mean;
     const float den = (float)sqrt((double)var + 1e-05);
+    float o4[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         float o = ((v[r] - mean) / den) * e_g[r] + e_b[r];
         if (a.post_gelu && !(STS_EXP & 1)) o = gelu_ref(o);
         if (a.res) o = e_res[r] + o;
-        a.y[(size_t)(row0 + r) * a.y_ld + base + pos] = o;
+        o4[r] = o;
+        if (!TAIL) a.y[(size_t)(row0 + r) * a.y_ld + base + pos] = o;
+    }
+    if constexpr (TAIL) {
+    // ---- 5. tail: 29 spline parameters per time step from the layer's output, then the reverse spline step.
+    // (every wave's reads of ys precede the barrier of stage 4: the block can be overwritten)
+    __shared__ float tp[32 * 16], wb[32];
+    __shared__ __attribute__((aligned(16))) float wl[C * 32];
+#pragma unroll
+    for (int r = 0; r < 4; r++) ys[(row0 + r) * 16 + col] = live ? o4[r] : 0.f;
+    reinterpret_cast<f32x4*>(wl)[tid] = tw0; reinterpret_cast<f32x4*>(wl)[tid + 64 * NSUB] = tw1;
+    if (tid < 32) wb[tid] = t_bias;
+    __syncthreads();
+    for (int j = tid >> 4; j < 32; j += 4 * NSUB) {                 // thread (parameter j, time step col): fp32 FMA chain over the C channels
+        float acc = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < C; c++) acc += wl[c * 32 + j] * ys[c * 16 + col];
+        acc += wb[j];
+        tp[j * 16 + col] = j < 29 ? rq_spline_param(j, acc, a.tp_fs) : 0.f;
+    }
+    __syncthreads();
+    if (tid < 16 && live) {
+        float t[29];
+#pragma unroll
+        for (int j = 0; j < 29; j++) t[j] = tp[j * 16 + tid];
+        a.tp_o0[base + pos] = rq_spline_inverse_t(t_in, t);
+        a.tp_o1[base + pos] = t_keep;
+    }
     }
 }
 
@@ -328,12 +366,21 @@ bool col_layer_eligible(const ColLayerArgs& a) {
     if (!a.wc || !a.g2 || !a.b2 || !a.x || !a.y) return false;
     if (a.dw_w && (!a.g1 || !a.b1 || a.dw_k < 1 || a.dw_k > 3)) return false;
     if (a.xs_w && (!a.dw_w || a.res != a.x)) return false;     // the folded input is defined for the DDSConv form only
+    if (a.tp_w && (a.C == 256 || !a.tp_b || !a.tp_o0 || !a.tp_o1 || a.tp_o0 == a.tp_r0 || a.tp_o0 == a.tp_r1 || a.tp_o1 == a.tp_r1)) return false;
     if (a.y == a.x) return false;               // other workgroups read x (halo of the depthwise conv) while this one writes y
     return a.max_len > 0 && a.B > 0;
 }
 
 void col_layer(const ColLayerArgs& a, hipStream_t st) {
     const dim3 grid((a.max_len + 15) / 16, a.B);
+    if (a.tp_w) {
+        switch (a.C) {
+            case 32: hipLaunchKernelGGL((col_layer_kernel<2, true>), grid, dim3(128), 0, st, a); break;
+            case 64: hipLaunchKernelGGL((col_layer_kernel<4, true>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((col_layer_kernel<12, true>), grid, dim3(768), 0, st, a); break;
+        }
+        return;
+    }
     switch (a.C) {
         case 32: hipLaunchKernelGGL((col_layer_kernel<2>), grid, dim3(128), 0, st, a); break;
         case 64: hipLaunchKernelGGL((col_layer_kernel<4>), grid, dim3(256), 0, st, a); break;

@@ -225,7 +225,9 @@ void Engine::ln(const DLn& l, const float* a, const float* b, const float* res, 
 // `pre` (optional): the ConvFlow's 1 -> C input conv, h = (pre(pre_in) + pre_res) (/root/reference/src/modules/ConvFlow.cpp:252-254;
 // pre_in == null: the all-zero latent).  Where the first layer runs fused, h is never materialised: the kernel evaluates it at its
 // depthwise taps; otherwise the conv runs first, into `h`.
-float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre, const float* pre_in, const float* pre_res) {
+float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre, const float* pre_in, const float* pre_res,
+                   const SplineTail* tail, bool* tail_done) {
+    if (tail_done) *tail_done = false;
     static const bool no_col = exp_flag("STS_NO_COL_LAYER");   // experiment knob
     float* cur = h;
     bool pre_pending = pre != nullptr;
@@ -263,6 +265,20 @@ float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv,
                 } else { g.x = cur; g.res = cur; g.xs_w = g.xs_b = g.xr = nullptr; }
             }
             run_pre();
+            if (tail && tail_done && dds_tail && i == d.n - 1 && tail->proj && tail->proj->k == 1 && !tail->proj->depthwise && tail->proj->Cout == 29 &&
+                tail->proj->Cout_pad == 32 && tail->proj->Cin == pw.Cin && tail->proj->Cin_pad == pw.Cin && tail->proj->w && tail->proj->bias) {
+                // the layer's output feeds only the projection: both and the spline step in this launch
+                ColLayerArgs gt = g;
+                gt.tp_w = tail->proj->w; gt.tp_b = tail->proj->bias; gt.tp_fs = tail->filter_sqrt;
+                gt.tp_r0 = tail->r0; gt.tp_r1 = tail->r1; gt.tp_o0 = tail->o0; gt.tp_o1 = tail->o1;
+                if (col_layer_eligible(gt)) {
+                    flops_[cur_stage_] += 2.0 * (c.macs_per_out + pw.macs_per_out + tail->proj->macs_per_out) * (double)lv.total;
+                    bytes_[cur_stage_] += 4.0 * ((double)pw.Cin * lv.total + (double)pw.Cin * pw.Cout + (double)pw.Cin * 32 + 4.0 * lv.total);
+                    col_layer(gt, cur_);
+                    *tail_done = true;
+                    return nxt;                 // (not written: the caller ignores it when the tail ran)
+                }
+            }
             if (col_layer_eligible(g)) {
                 flops_[cur_stage_] += 2.0 * (c.macs_per_out + pw.macs_per_out) * (double)lv.total;
                 bytes_[cur_stage_] += 4.0 * ((double)pw.Cin * lv.total * 2.0 + (double)pw.Cin * pw.Cout);
@@ -648,9 +664,13 @@ int Engine::run_durations(RunCtx& c) {
         for (int i = M.sdp_flows - 1; i > 0; i--) {   // flow 0 is skipped; z == 0 because noise_scale == 0
             const DConvFlow& cf = M.cf[i];
             // DDSConv(pre(x0) + g): the 1 -> C input conv and the "+ g" ride inside the first DDSConv layer
-            const float* dhh = dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT, &cf.pre, r0, bt.dc);
-            conv(cf.proj, dhh, lvT, bt.dp29, lvT, ConvOpt());
-            spline_step(bt.dp29, Ttot, sqrtf((float)cf.filter), r0, r1, n0, n1, Ttot, stream);
+            const SplineTail tl{&cf.proj, sqrtf((float)cf.filter), r0, r1, n0, n1};
+            bool tail_done = false;
+            const float* dhh = dds(cf.dds, bt.dhh, bt.dt1, bt.dt2, lvT, &cf.pre, r0, bt.dc, &tl, &tail_done);
+            if (!tail_done) {
+                conv(cf.proj, dhh, lvT, bt.dp29, lvT, ConvOpt());
+                spline_step(bt.dp29, Ttot, sqrtf((float)cf.filter), r0, r1, n0, n1, Ttot, stream);
+            }
             r0 = n0; r1 = n1;
             float* t;
             t = n0; n0 = s0; s0 = t;

@@ -79,6 +79,7 @@ public:
     long h2_fallbacks = 0;             // runs repeated in split-bf16 because an activation left fp16's range (conv_math 3)
     int h2_consecutive = 0; bool h2_disabled = false;   // two repeats in a row: the engine stays on split-bf16 until sts_set_conv_math
     double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
+    int dds_tail = 1;                  // 1: a ConvFlow's 29-row projection and spline step ride in its last DDSConv layer's launch (col_layer.hip tail) (STS_DBG_DDS_TAIL)
     int attn_reg = 1;                  // 1: one-query attention with its operands in registers (attention_reg_kernel) where the shape allows (STS_DBG_ATTN_REG)
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
     int launch_ahead = 1;              // 1: a one-utterance call enqueues flow + decoder before the frame count is on the host (sts_debug_set STS_DBG_LAUNCH_AHEAD)
@@ -101,8 +102,10 @@ private:
     void conv(const DConv& c, const float* x, const Lvl& lin, float* y, const Lvl& lout, const ConvOpt& o);
     void ln(const DLn& l, const float* a, const float* b, const float* res, float* y, const Lvl& lv, int pre_relu, int post_gelu, int nb = 1, long b_stride = 0);
     int pick_kslices(const DConv& c, const Lvl& lout) const;
+    // (tail: the ConvFlow's projection + reverse spline step, run inside the last layer's launch when it can take them; *tail_done says so)
+    struct SplineTail { const DConv* proj; float filter_sqrt; const float* r0; const float* r1; float* o0; float* o1; };
     float* dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv, const DConv* pre = nullptr, const float* pre_in = nullptr,
-               const float* pre_res = nullptr);
+               const float* pre_res = nullptr, const SplineTail* tail = nullptr, bool* tail_done = nullptr);
     struct RunCtx;                  // what the stages of one run share (engine.hip)
     int run_setup(RunCtx& c);
     int run_text_encoder(RunCtx& c);

@@ -116,6 +116,13 @@ struct ColLayerArgs {
     float* y; long y_ld;
     int C;
     SegView seg; int B, max_len;
+    // optional tail (the last DDSConv layer of a ConvFlow of the stochastic duration predictor): the layer's output stays in LDS, the
+    // 1x1 projection to the 29 spline parameters (/root/reference/src/modules/ConvFlow.cpp:256-258) and the reverse spline step with
+    // the channel flip (StochasticDurationPredictor.cpp:136-142: (r0, r1) -> (spline(r1 | h), r0)) run in the same launch; y is not written
+    const float* tp_w; const float* tp_b;       // projection weights [C][32] (cin-major, rows >= 29 zero) and bias [29]; null: no tail
+    float tp_fs;                                // sqrt(filter channels)
+    const float* tp_r0; const float* tp_r1;     // latent halves in (null: zeros)
+    float* tp_o0; float* tp_o1;                 // latent halves out
 };
 bool col_layer_eligible(const ColLayerArgs& a);
 bool col_layer_width_ok(int C);

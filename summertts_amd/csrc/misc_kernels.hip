@@ -659,59 +659,7 @@ void flip_channels(float* x, long ld, int C, long n, float* tmp, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Inverse rational-quadratic spline, 10 bins, linear tails outside (-5, 5).
-// /root/reference/src/modules/ConvFlow.cpp:80-240 (+ searchsorted :57-78, on the cumulative HEIGHTS
-// because this is the inverse direction).  Everything lives in registers; one thread per time step.
-__device__ float rq_spline_inverse(float x, const float* h, float filter_sqrt) {
-    constexpr int NB = 10;
-    const float tail = 5.0f;
-    if (!(x < tail && x > -tail)) return x;
-    float uw[NB], uh[NB];
-    float sw = 0.f, sh = 0.f;
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        uw[i] = expf(h[i] / filter_sqrt); sw += uw[i];
-        uh[i] = expf(h[NB + i] / filter_sqrt); sh += uh[i];
-    }
-    float cw[NB + 1], ch[NB + 1], der[NB + 1];
-    float aw = 0.f, ah = 0.f;
-    cw[0] = -tail; ch[0] = -tail;
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        const float w = (uw[i] / sw) * (float)(1 - 1e-3 * NB) + (float)1e-3;
-        const float hh = (uh[i] / sh) * (float)(1 - 1e-3 * NB) + (float)1e-3;
-        aw += w; ah += hh;
-        cw[i + 1] = aw * (tail - (-tail)) + (-tail);
-        ch[i + 1] = ah * (tail - (-tail)) + (-tail);
-    }
-    cw[NB] = tail; ch[NB] = tail;
-    der[0] = softplus_ref(0.5397424172369522f) + (float)1e-3;
-    der[NB] = der[0];
-#pragma unroll
-    for (int i = 1; i < NB; i++) der[i] = softplus_ref(h[2 * NB + i - 1]) + (float)1e-3;
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j <= NB; j++) {
-        float edge = ch[j];
-        if (j == NB) edge = edge + 1e-6f;
-        cnt += (x >= edge) ? 1 : 0;
-    }
-    int bi = cnt - 1;
-    bi = bi < 0 ? 0 : (bi > NB - 1 ? NB - 1 : bi);   // the reference would assert out of range
-    float in_cw = 0.f, in_w = 0.f, in_ch = 0.f, in_h = 0.f, d0 = 0.f, d1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < NB; j++)
-        if (j == bi) { in_cw = cw[j]; in_w = cw[j + 1] - cw[j]; in_ch = ch[j]; in_h = ch[j + 1] - ch[j]; d0 = der[j]; d1 = der[j + 1]; }
-    const float delta = in_h / in_w;
-    const float xm = x - in_ch;
-    const float aa = xm * (d0 + d1 - delta * 2.0f) + in_h * (delta - d0);
-    const float bq = in_h * d0 - xm * (d0 + d1 - 2.0f * delta);
-    const float cc = -(delta * xm);
-    const float disc = bq * bq - aa * cc * 4.0f;
-    const float root = (cc * 2.0f) / (-bq - sqrtf(disc));
-    return root * in_w + in_cw;
-}
-
+// (the inverse rational-quadratic spline itself: devmath.hpp rq_spline_inverse)
 // one reverse ConvFlow step of the stochastic duration predictor including the channel flip
 // (/root/reference/src/models/StochasticDurationPredictor.cpp:136-142): (r0, r1) -> (spline(r1 | h), r0)
 __global__ void spline_step_kernel(const float* h, long ld, float fs, const float* r0, const float* r1,
