@@ -136,6 +136,7 @@ int sts_set_conv_math(sts_engine* e, int mode);
  *   (0, 1) and answers STS_EINVAL to 2. */
 enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2, STS_DBG_PK_TRACE = 3 /* per-op timeline of the persistent kernel -> tap "pk_trace" */,
        STS_DBG_TRUNK_MODE = 4 /* 128-channel decoder stage of a one-utterance call: 0 automatic, 1 grouped launches, 2 one persistent launch per stage */,
+       STS_DBG_PCM_DIRECT = 9 /* sts_set_host_pcm(1), one utterance: 1 (default) the decoder's last kernel writes the PCM into the pinned host buffer itself, 0 a download behind it */,
        STS_DBG_DDS_TAIL = 8 /* stochastic duration predictor: 1 (default) a ConvFlow's projection + spline step ride in its last DDSConv layer's launch, 0 three launches */,
        STS_DBG_ATTN_REG = 7 /* one-query attention: 1 (default) operands in registers (attention_reg_kernel), 0 the round-1 kernel */,
        STS_DBG_LAUNCH_AHEAD = 6 /* one-utterance calls: 1 (default) flow + decoder are enqueued for a predicted frame capacity before the count reaches the host, 0 the host waits for it */,

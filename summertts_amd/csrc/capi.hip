@@ -61,7 +61,9 @@ int sts_run_batch(sts_engine* e, int32_t B, const int32_t* const* ids, const int
 int sts_copy_pcm_device(sts_engine* e, void* dst, int64_t cap) {
     if (!e || !dst) return set_err(STS_EINVAL, "null argument");
     if (cap < e->eng.total_samples || !e->eng.d_pcm) return set_err(STS_ESTATE, "destination too small or no run yet");
-    if (hipMemcpyAsync(dst, e->eng.d_pcm, (size_t)e->eng.total_samples * 2, hipMemcpyDeviceToDevice, e->eng.stream) != hipSuccess ||
+    // (d_pcm is the mapped pinned host buffer when the run's last kernel wrote the PCM there: Engine::pcm_in_host_)
+    if (hipMemcpyAsync(dst, e->eng.pcm_in_host_ ? (const void*)e->eng.h_pcm : (const void*)e->eng.d_pcm, (size_t)e->eng.total_samples * 2,
+                       e->eng.pcm_in_host_ ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e->eng.stream) != hipSuccess ||
         hipStreamSynchronize(e->eng.stream) != hipSuccess)
         return set_err(STS_EDEVICE, "device copy failed");
     return STS_OK;
@@ -161,6 +163,7 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_LAUNCH_AHEAD: e->eng.launch_ahead = value != 0; return STS_OK;
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
         case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
+        case STS_DBG_PCM_DIRECT: e->eng.pcm_direct = value != 0; return STS_OK;
 #ifdef STS_EXPERIMENTS
         case STS_DBG_FRONT_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "front mode must be 0, 1 or 2"); e->eng.front_mode = value; return STS_OK;
         case STS_DBG_TRUNK_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "trunk mode must be 0, 1 or 2"); e->eng.trunk_mode = value; return STS_OK;

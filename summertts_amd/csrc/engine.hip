@@ -799,14 +799,16 @@ int Engine::frame_geometry(RunCtx& c) {
         // (a single utterance carries its geometry in the kernel arguments: nothing on the device reads these tables)
         if (!c.inl || ss) HIPCK(hipMemcpyAsync(c.d_offF, p_offF, (size_t)(5 * B + 2) * 4, hipMemcpyHostToDevice, stream));
     }
-    h_pcm = nullptr;
+    h_pcm = nullptr; pcm_in_host_ = false;
     if (host_pcm && !ss) {   // room for the PCM download that rides at the end of this run
         const size_t need = (size_t)c.Fld * hop * 2 + 256;
         if (need > pinned_pcm_cap_) {
             if (pinned_pcm_) (void)hipHostFree(pinned_pcm_);
             pinned_pcm_ = nullptr; pinned_pcm_cap_ = 0;
-            if (hipHostMalloc((void**)&pinned_pcm_, need + need / 2, hipHostMallocDefault) != hipSuccess) return fail(STS_EDEVICE, "pinned host allocation failed");
+            pinned_pcm_dev_ = nullptr;
+            if (hipHostMalloc((void**)&pinned_pcm_, need + need / 2, hipHostMallocMapped) != hipSuccess) return fail(STS_EDEVICE, "pinned host allocation failed");
             pinned_pcm_cap_ = need + need / 2;
+            if (hipHostGetDevicePointer((void**)&pinned_pcm_dev_, pinned_pcm_, 0) != hipSuccess) { pinned_pcm_dev_ = nullptr; (void)hipGetLastError(); }
         }
     }
     return STS_OK;
@@ -887,6 +889,13 @@ int Engine::run_frame_workspace(RunCtx& c) {
     arenaF_.measuring = true; layoutF(arenaF_);
     if (!ensure(arenaF_, arenaF_.used + 4096)) return fail(STS_EDEVICE, "out of device memory (frame-level workspace)");
     arenaF_.measuring = false; layoutF(arenaF_);
+    // one short utterance with the PCM wanted on the host: the decoder's last kernel stores its int16 samples into the mapped pinned
+    // buffer itself (posted writes over the host link, under the kernel's own run time) instead of a download queued behind it
+    if (pcm_direct && host_pcm && !ss && B == 1 && !record_taps && pinned_pcm_dev_ && (size_t)Wcap * hop * 2 + 256 <= pinned_pcm_cap_ &&
+        (size_t)Wcap * hop * 2 <= ((size_t)4 << 20)) {
+        bf.pcm = pinned_pcm_dev_;
+        pcm_in_host_ = true;
+    }
 
     Lvl& lv1 = c.lv1; lv1 = Lvl(); lv1.seg = (inl && !c.ahead) ? SegView{nullptr, nullptr, 1, 0, 0, p_lenF[0]} : SegView{d_offF, d_lenF, 1, 0, 0, 0};
     lv1.nb = B; lv1.max_len = maxF; lv1.total = Ftot; lv1.ld = Ftot;
@@ -1544,7 +1553,7 @@ int Engine::run_output(RunCtx& c) {
         if (ahead) {
             // everything is enqueued.  The PCM download is queued for the CAPACITY (<= 63 frames more than needed) and the run's one
             // stream synchronisation happens before the count is looked at: the host never waits for the count by itself
-            if (host_pcm) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)Fld * hop * 2, hipMemcpyDeviceToHost, stream));
+            if (host_pcm && !pcm_in_host_) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)Fld * hop * 2, hipMemcpyDeviceToHost, stream));
             host_us_enq_ = (float)(now_us() - host_t0_);
             HIPCK(hipStreamSynchronize(stream));
             host_t_sync_ = now_us();
@@ -1570,7 +1579,7 @@ int Engine::run_output(RunCtx& c) {
         d_pcm = bf.pcm;
         total_samples = Fcount * hop;
         if (host_pcm) {
-            if (!ahead) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)total_samples * 2, hipMemcpyDeviceToHost, stream));
+            if (!ahead && !pcm_in_host_) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)total_samples * 2, hipMemcpyDeviceToHost, stream));
             h_pcm = (const int16_t*)pinned_pcm_;
         }
         if (!ahead) {

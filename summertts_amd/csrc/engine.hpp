@@ -66,6 +66,7 @@ public:
     int16_t* d_pcm = nullptr;          // device, packed
     float host_us_setup_ = 0, host_us_enq_ = 0;
     double host_t0_ = 0, host_t_sync_ = 0;   // steady-clock microseconds: entry of the run, return of its last stream synchronisation
+    bool pcm_in_host_ = false;         // this run's PCM was written by the kernels into the pinned host buffer (d_pcm is its device-side address; no HBM copy exists)
     const int16_t* h_pcm = nullptr;    // host copy of the last run's PCM (pinned, engine-owned) when host_pcm is set, else null
     bool host_pcm = false;             // download the PCM as part of run(): one stream sync per call instead of two
     std::vector<int32_t> durations_h;  // packed
@@ -79,6 +80,7 @@ public:
     long h2_fallbacks = 0;             // runs repeated in split-bf16 because an activation left fp16's range (conv_math 3)
     int h2_consecutive = 0; bool h2_disabled = false;   // two repeats in a row: the engine stays on split-bf16 until sts_set_conv_math
     double products() const { return conv_math == 3 ? 3.0 : 6.0; }     // 16-bit matrix products per fp32 product
+    int pcm_direct = 1;                // 1: with host_pcm, a one-utterance call's last kernel writes the PCM into the pinned host buffer itself (no download behind it) (STS_DBG_PCM_DIRECT)
     int dds_tail = 1;                  // 1: a ConvFlow's 29-row projection and spline step ride in its last DDSConv layer's launch (col_layer.hip tail) (STS_DBG_DDS_TAIL)
     int attn_reg = 1;                  // 1: one-query attention with its operands in registers (attention_reg_kernel) where the shape allows (STS_DBG_ATTN_REG)
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
@@ -127,6 +129,7 @@ private:
     Arena arenaT_, arenaF_;
     char* pinned_ = nullptr; size_t pinned_cap_ = 0;
     char* pinned_pcm_ = nullptr; size_t pinned_pcm_cap_ = 0;
+    int16_t* pinned_pcm_dev_ = nullptr;   // the same buffer as the GPU sees it (mapped): the last kernel of a small call writes the PCM straight into it
     unsigned* ovf_host_ = nullptr; unsigned* ovf_ = nullptr;              // conv_math 3: overflow word (host-mapped) and its device address
     int* hmap_ = nullptr; int* hmap_dev_ = nullptr; size_t hmap_cap_ = 0;   // host-mapped result block of the durations kernel
     unsigned* arrive_ = nullptr; int seq_ = 0;

@@ -763,10 +763,19 @@ __global__ __launch_bounds__(256) void expand_frames_kernel(const float* m, long
     const int b = blockIdx.z;
     const int F = seg_len(segF, b), T = seg_len(segT, b);
     const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= F) return;
+    if (blockIdx.x * 256 >= F) return;
     const size_t tb = (size_t)seg_start(segT, b), fb = (size_t)seg_start(segF, b);
+    // the binary search is a chain of ~log2(T) dependent reads: through LDS (one trip to L2 for the whole table) instead of ~7 trips
+    __shared__ int cs[1024];
+    const bool staged = T <= 1024;
+    if (staged) {
+        for (int i = threadIdx.x; i < T; i += 256) cs[i] = cum[tb + i];
+        __syncthreads();
+    }
+    if (f >= F) return;
     int lo = 0, hi = T;   // first i with cum[i] > f
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (cum[tb + mid] > f) hi = mid; else lo = mid + 1; }
+    if (staged) { while (lo < hi) { int mid = (lo + hi) >> 1; if (cs[mid] > f) hi = mid; else lo = mid + 1; } }
+    else { while (lo < hi) { int mid = (lo + hi) >> 1; if (cum[tb + mid] > f) hi = mid; else lo = mid + 1; } }
     const int c0 = blockIdx.y * 16, c1 = c0 + 16 < C ? c0 + 16 : C;
     if (lo >= T) { for (int c = c0; c < c1; c++) z[(size_t)c * z_ld + fb + f] = 0.f; return; }
 #pragma unroll 4

@@ -256,7 +256,7 @@ class Synthesizer:
 
     def debug_set(self, key: str, value: int):
         """Test hooks (include/summertts_hip.h sts_debug_set): 'attn_block_min_wgs' | 'front_mode'."""
-        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "front_mode": 2, "pk_trace": 3, "trunk_mode": 4, "flow_fused": 5, "launch_ahead": 6, "attn_reg": 7, "dds_tail": 8}[key], int(value)))
+        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "front_mode": 2, "pk_trace": 3, "trunk_mode": 4, "flow_fused": 5, "launch_ahead": 6, "attn_reg": 7, "dds_tail": 8, "pcm_direct": 9}[key], int(value)))
 
     def set_profiling(self, on: bool):
         _check(self.lib, self.lib.sts_set_profiling(self.h, 1 if on else 0))

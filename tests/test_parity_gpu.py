@@ -980,6 +980,22 @@ def test_prepared_batch_and_host_view_return_the_copied_samples():
         assert np.array_equal(view, np.concatenate(want)) and np.array_equal(syn.pcm_host(), view)
     p = syn.profile()
     assert p["us_host_setup"] > 0 and p["us_host_enqueue"] >= p["us_host_setup"] and p["us_host_tail"] >= 0
+    # one utterance: the decoder's last kernel writes the PCM into the pinned host buffer itself (STS_DBG_PCM_DIRECT); the download
+    # behind the run must hand over the same samples, and a device-side copy-out must still work from either
+    one = syn.prepare(ids[:1], sid[:1], ls[:1])
+    import torch
+    base = None
+    for direct in (0, 1, 0, 1):
+        syn.debug_set("pcm_direct", direct)
+        n1 = syn.run_batch(one)
+        got = syn.pcm_host()
+        if base is None:
+            base = got
+            assert_pcm_close(base, utts[0][5], "one utterance vs the reference")
+        assert got.size == int(n1[0]) and np.array_equal(got, base) and np.array_equal(syn.pcm_host(copy=False), base), f"pcm_direct={direct}"
+        dev = torch.empty(int(n1[0]), dtype=torch.int16, device="cuda")
+        syn.pcm_to_device_ptr(dev.data_ptr(), dev.numel())
+        assert np.array_equal(dev.cpu().numpy(), base)
     syn.set_host_pcm(False)
     syn.run_batch(prep)
     with pytest.raises(engine.StsError):

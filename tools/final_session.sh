@@ -11,6 +11,11 @@ timeout 400 python bench.py --config 3 --steps 5 --warmup 2 --cpu-reps 1 --cpu-t
 timeout 400 python bench.py --config 4 --steps 5 --warmup 2 --cpu-reps 1 --cpu-threads 16 --pipeline-engines 0 > $O/bench_c4.json 2> $O/bench_c4.err
 STS_BENCH_FORCE_DIST=1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --min-seconds 0 > $O/bench_c1_rccl1rank.json 2> $O/bench_c1_rccl1rank.err
 timeout 200 python tools/power_trace.py 5 > $O/power_trace.log 2>&1
+# same-box A/B of the PCM hand-over (the last kernel writes into the pinned host buffer vs a download behind it)
+for v in 1 0 1 0; do timeout 100 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-f32-leg --pipeline-engines 0 --min-seconds 0 --debug-set pcm_direct=$v 2> /dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('pcm_direct=$v', round(d['ms_per_step'],4), d['stage_ms_per_step'], d['host_us_per_step']['step_wall_minus_device_stages'])" >> $O/pcm_direct_ab.txt; done
+cat $O/pcm_direct_ab.txt
 if [ -f summertts_amd/lib/var/libvar6tt.so ]; then
   SUMMERTTS_HIP_LIB=summertts_amd/lib/var/libvar6tt.so timeout 200 python tools/tile_trace_dump.py $O/tt_b1.npz 1 > $O/tt.log 2>&1
 fi
