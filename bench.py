@@ -661,7 +661,7 @@ def main():
                                            {"tflops_fp32_equivalent": (SUSTAINED_F16_TWO_TERM_TFLOPS if products == 3 else SUSTAINED_BF16_SPLIT_TFLOPS) / products,
                                             "frac": achieved_tf / ((SUSTAINED_F16_TWO_TERM_TFLOPS if products == 3 else SUSTAINED_BF16_SPLIT_TFLOPS) / products),
                                             "measured": False,
-                                            "source": "tools/ubench/libsts_ubench.so not built: the constant of the arithmetic that ran ("
+                                            "source": "not measured in this run (a multi-rank / forced-distributed run, or tools/ubench/libsts_ubench.so not built): the constant of the arithmetic that ran ("
                                                       + ("1490 fp16 TF/s on two-term planes, round 3" if products == 3 else "1712 bf16 TF/s on three-term planes, round 2")
                                                       + " of the nominal 2500)"}) if split else None,
                 "bf16_issued_tflops": bf16_tf,
