@@ -69,6 +69,22 @@ def test_fails_loudly_without_gpu(lib):
         engine.debug_conv1d(np.zeros((4, 8), np.float32), np.zeros((4, 1, 4), np.float32), None, 0)
 
 
+def test_prepared_batch_builds_the_argument_arrays_of_run_batch():
+    """Synthesizer.prepare (engine.PreparedBatch): the arrays sts_run_batch takes, built once -- ragged ids, defaults for speaker ids and
+    length scales, and pointers that stay valid for the life of the object (the bench step re-submits one object every step)."""
+    import ctypes as C
+    ids = [[1, 2, 3], np.arange(7, dtype=np.int64), (4,)]
+    p = engine.PreparedBatch(ids)
+    assert len(p) == 3 and p.n.tolist() == [3, 7, 1] and p.n.dtype == np.int32
+    assert p.sid.tolist() == [0, 0, 0] and p.ls.tolist() == [1.0, 1.0, 1.0] and p.ls.dtype == np.float32
+    for b, want in enumerate(ids):
+        got = np.ctypeslib.as_array(C.cast(p.ptrs[b], C.POINTER(C.c_int32)), shape=(len(want),))
+        assert got.tolist() == [int(v) for v in want]
+    assert (p.n_p, p.sid_p, p.ls_p, p.n_out_p) == (p.n.ctypes.data, p.sid.ctypes.data, p.ls.ctypes.data, p.n_out.ctypes.data)
+    q = engine.PreparedBatch(ids, sid=[2, 0, 1], length_scale=[0.5, 1.0, 2.0])
+    assert q.sid.tolist() == [2, 0, 1] and q.ls.tolist() == [0.5, 1.0, 2.0]
+
+
 def test_product_never_touches_the_oracle():
     # the oracle is test infrastructure: nothing under summertts_amd/ may import, link or dlopen it
     for dirpath, _, files in os.walk(os.path.join(ROOT, "summertts_amd")):
