@@ -91,3 +91,17 @@ def test_three_products_of_the_scaled_two_term_form_match_an_fp32_chain_at_every
         if sx <= 0.001:
             naive = sn.mfma_sum(sn.split_f16x2(A), sn.split_f16x2(B), [(1, 0), (0, 1), (0, 0)], K)
             assert np.sqrt(((naive - truth) ** 2).mean()) / s > 5 * e
+
+
+def test_winograd_domain_operands_survive_the_two_term_split():
+    """tools/wino_f16x2_numerics.py: the segmented F(2,3) / F(2,2) form of a dilated ResBlock conv -- input transform in
+    fp32, weight transform in float64, then the shipped two-term fp16 split with ONE power-of-two scale per conv -- is at least as
+    accurate as the shipped direct two-term form and as an fp32 multiply-add chain, with 4 n3 + 3 n2 instead of 2 k matrix products per
+    output pair.  (A statement about the arithmetic only: no such kernel is shipped.)"""
+    import wino_f16x2_numerics as wn
+    assert [wn.wino_split(k) for k in (3, 7, 11, 5, 2)] == [(1, 0), (1, 2), (3, 1), (1, 1), (0, 1)]
+    for k, dil, sx in ((3, 5, 1.0), (7, 3, 0.01), (11, 1, 1.0)):
+        r = wn.study(k, dil, sx, seed=11, Cin=64, Cout=32, N=120)
+        assert r["winograd f16x2"] <= 1.05 * r["direct f16x2 (shipped)"], (k, dil, sx, r)
+        assert r["winograd f16x2"] <= r["fp32 chain"], (k, dil, sx, r)
+        assert r["winograd exact-fp32 (shipped f32 path)"] <= r["winograd f16x2"] * 1.05, (k, dil, sx, r)
