@@ -130,16 +130,13 @@ int sts_set_conv_math(sts_engine* e, int mode);
 /*   test hooks (per engine, never read from the environment): force a kernel family that the automatic choice would not pick
  *   at the size of a test.  key: STS_DBG_ATTN_BLOCK_MIN_WGS -- the matrix-core block attention kernel engages from this many
  *   workgroups on (default 96; 1 = always).
- *   STS_DBG_FRONT_MODE / STS_DBG_TRUNK_MODE / STS_DBG_PK_TRACE select the two persistent-kernel families of round 3 (persist.hip,
- *   conv_bf3_stage_kernel).  Both lost their A/B against the launch path, so they exist only in the lab build
- *   (`make -C summertts_amd/csrc exp`, -DSTS_EXPERIMENTS); the shipped library accepts the values that mean "the launch path"
- *   (0, 1) and answers STS_EINVAL to 2. */
-enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1, STS_DBG_FRONT_MODE = 2, STS_DBG_PK_TRACE = 3 /* per-op timeline of the persistent kernel -> tap "pk_trace" */,
-       STS_DBG_TRUNK_MODE = 4 /* 128-channel decoder stage of a one-utterance call: 0 automatic, 1 grouped launches, 2 one persistent launch per stage */,
+ *   (Keys 2-4 selected the two persistent-kernel families of round 3; both lost their A/B against the launch path and were deleted
+ *   in round 5 -- the numbers stay retired and answer STS_EINVAL.) */
+enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1,
        STS_DBG_PCM_DIRECT = 9 /* sts_set_host_pcm(1), one utterance: 1 (default) the decoder's last kernel writes the PCM into the pinned host buffer itself, 0 a download behind it */,
        STS_DBG_DDS_TAIL = 8 /* stochastic duration predictor: 1 (default) a ConvFlow's projection + spline step ride in its last DDSConv layer's launch, 0 three launches */,
        STS_DBG_ATTN_REG = 7 /* one-query attention: 1 (default) operands in registers (attention_reg_kernel), 0 the round-1 kernel */,
-       STS_DBG_LAUNCH_AHEAD = 6 /* one-utterance calls: 1 (default) flow + decoder are enqueued for a predicted frame capacity before the count reaches the host, 0 the host waits for it */,
+       STS_DBG_LAUNCH_AHEAD = 6 /* one-utterance calls: 1 (default) a request the engine has served before (same ids, speaker, length scale: the frame count is a pure function of them) enqueues flow + decoder before the count reaches the host, 0 the host always waits for it, 2 (tests) the memo is keyed by the phoneme count alone -- provokes the repeat that answers a hash collision */,
        STS_DBG_FLOW_FUSED = 5 /* reverse flow: 1 (default) one launch per WaveNet layer (wn_flow.hip, under the two-term fp16 arithmetic), 0 one launch per conv */ };
 int sts_debug_set(sts_engine* e, int key, int value);
 
@@ -173,7 +170,7 @@ int sts_set_profiling(sts_engine* e, int enable);
  * when client and library are built together. */
 #define STS_ABI_VERSION 6
 int sts_abi_version(void);
-/* bit 0: lab build (-DSTS_EXPERIMENTS: environment knobs of knobs.hpp, the persistent-kernel families, every conv tile code);
+/* bit 0: lab build (-DSTS_EXPERIMENTS: environment knobs of knobs.hpp, every conv tile code);
  * 0 for the shipped library */
 int sts_build_flags(void);
 int sts_get_profile(const sts_engine* e, sts_profile* p);
@@ -236,7 +233,9 @@ int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* de
 int sts_multi_gather_mode(const sts_multi* m);
 /*   test hook: the shared library that provides the nccl* entry points (NULL / "" = librccl.so.1) and whether STS_MULTI_RCCL may list
  *   one device several times (tests/fake_rccl: N emulated ranks on one GPU; real RCCL refuses duplicates).  Only before the first
- *   STS_MULTI_RCCL handle of the process is created. */
+ *   STS_MULTI_RCCL handle of the process is created.  TEST-ONLY: refused with STS_ESTATE unless the process environment carries
+ *   STS_TEST_HOOKS=1, so that no caller of the drop-in library substitutes the collective library or lifts the distinct-device check
+ *   by accident. */
 int sts_multi_set_rccl_library(const char* path, int allow_repeated_devices);
 /*   layout of the gather buffer (host arithmetic only): rank r's block starts at offsets[r] samples (256-byte aligned);
  *   returns the buffer's extent in samples */

@@ -160,20 +160,10 @@ int sts_debug_set(sts_engine* e, int key, int value) {
     switch (key) {
         case STS_DBG_ATTN_BLOCK_MIN_WGS: if (value < 1) return set_err(STS_EINVAL, "threshold must be >= 1"); e->eng.attn_block_min_wgs = value; return STS_OK;
         case STS_DBG_FLOW_FUSED: e->eng.flow_fused = value != 0; return STS_OK;
-        case STS_DBG_LAUNCH_AHEAD: e->eng.launch_ahead = value != 0; return STS_OK;
+        case STS_DBG_LAUNCH_AHEAD: if (value < 0 || value > 2) return set_err(STS_EINVAL, "launch_ahead must be 0, 1 or 2"); if ((value == 2) != (e->eng.launch_ahead == 2)) e->eng.seen_tf_.clear(); e->eng.launch_ahead = value; return STS_OK;
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
         case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
         case STS_DBG_PCM_DIRECT: e->eng.pcm_direct = value != 0; return STS_OK;
-#ifdef STS_EXPERIMENTS
-        case STS_DBG_FRONT_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "front mode must be 0, 1 or 2"); e->eng.front_mode = value; return STS_OK;
-        case STS_DBG_TRUNK_MODE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "trunk mode must be 0, 1 or 2"); e->eng.trunk_mode = value; return STS_OK;
-        case STS_DBG_PK_TRACE: e->eng.pk_trace = value != 0; return STS_OK;
-#else
-        // the persistent-kernel families exist only in the lab build (`make -C summertts_amd/csrc exp`): the shipped library has one path
-        case STS_DBG_FRONT_MODE: case STS_DBG_TRUNK_MODE: case STS_DBG_PK_TRACE:
-            if (value == 0 || (key != STS_DBG_PK_TRACE && value == 1)) return STS_OK;       // "automatic" / "the launch path": what this build always does
-            return set_err(STS_EINVAL, "this key selects a lab-only kernel family: build with -DSTS_EXPERIMENTS (make exp)");
-#endif
         default: return set_err(STS_EINVAL, "unknown debug key");
     }
 }

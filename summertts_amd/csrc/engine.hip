@@ -33,14 +33,6 @@ Engine::~Engine() {
     if (ovf_host_) (void)hipHostFree(ovf_host_);
     if (hmap_) (void)hipHostFree(hmap_);
     if (arrive_) (void)hipFree(arrive_);
-#ifdef STS_EXPERIMENTS
-    if (ps_priv_) (void)hipFree(ps_priv_);
-    if (ps_tab_) (void)hipFree(ps_tab_);
-    if (ps_tab_host_) (void)hipHostFree(ps_tab_host_);
-    if (ps_ctr_) (void)hipFree(ps_ctr_);
-    if (pk_prog_) (void)hipFree(pk_prog_);
-    if (pk_ctr_) (void)hipFree(pk_ctr_);
-#endif
     if (have_events_) {
         for (auto& e : ev_) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_fork_);
@@ -306,80 +298,6 @@ float* Engine::dds(const DDds& d, float* h, float* t1, float* t2, const Lvl& lv,
     return cur;
 }
 
-#ifdef STS_EXPERIMENTS   // lab build only: the persistent single-launch flow (persist.hip) lost to the launch-per-layer path
-// The reverse flow as ONE persistent launch (persist.hip): the op list of ResidualCouplingBlock.cpp:59-70 / ResidualCouplingLayer.cpp:47-66 /
-// WN.cpp:100-149 in execution order, every op annotated with the halo its output still needs (the receptive field of all the ops
-// behind it).  Static per model; built and uploaded on first use.
-bool Engine::flow_program() {
-    if (pk_state_) return pk_state_ > 0;
-    pk_state_ = -1;
-    const Model& M = model;
-    if (M.n_flows <= 0 || (M.n_flows & 1)) return false;       // an odd count ends with a channel reversal of z (flip_channels)
-    const int C = M.inter, half = C / 2;
-    auto conv_ok = [](const DConv& c) {
-        return !c.depthwise && !c.transposed && c.Cin >= 32 && c.Cin_pad % 8 == 0 && c.Cout_pad % 32 == 0 && (c.k & 1) &&
-               c.pad == c.dil * (c.k - 1) / 2 && c.wk8 != nullptr && c.Cin % 4 == 0 && c.Cout % 4 == 0;
-    };
-    if ((M.inter / 2) % 4 != 0) return false;
-    std::vector<int> R(M.n_flows, 0);
-    for (int i = 0; i < M.n_flows; i++) {
-        const DCoupling& cp = M.cp[i];
-        const DWn& w = cp.wn;
-        if (!conv_ok(cp.pre) || !conv_ok(cp.post) || cp.pre.k != 1 || cp.post.k != 1 || w.n < 1 || w.H % 16 != 0) return false;
-        if (cp.pre.Cin != half || cp.pre.Cout != w.H || cp.post.Cin != w.H || cp.post.Cout != half) return false;
-        for (int l = 0; l < w.n; l++) {
-            if (!conv_ok(w.in[l]) || !conv_ok(w.rs[l]) || !w.in[l].gate_perm || w.rs[l].k != 1) return false;
-            if (w.in[l].Cin != w.H || w.in[l].Cout != 2 * w.H || w.rs[l].Cin != w.H) return false;
-            if (w.rs[l].Cout != (l + 1 < w.n ? 2 * w.H : w.H)) return false;
-            R[i] += w.in[l].dil * (w.in[l].k - 1) / 2;
-        }
-        if (w.H != M.cp[0].wn.H || w.n != M.cp[0].wn.n) return false;
-    }
-    std::vector<PkStep> P;
-    auto conv_step = [&](const DConv& c, int halo, int epi, int in_buf, int in_row, int out_buf, int out_row) {
-        PkStep s;
-        memset(&s, 0, sizeof(s));
-        s.kind = PK_CONV; s.halo = halo; s.w = c.wk8; s.bias = c.bias; s.ubias_off = -1;
-        s.Cin = c.Cin; s.Cout = c.Cout; s.Cin_pad = c.Cin_pad; s.Cout_pad = c.Cout_pad; s.ntap = c.k; s.tap_step = c.dil; s.tap_off = -c.pad;
-        s.epi = epi; s.H = c.H; s.gate_perm = c.gate_perm;
-        s.in_buf = in_buf; s.in_row = in_row; s.out_buf = out_buf; s.out_row = out_row; s.aux_buf = 3;
-        return s;
-    };
-    int total = 0;
-    for (int r : R) total += r;
-    { PkStep s; memset(&s, 0, sizeof(s)); s.kind = PK_EXPAND; s.halo = total; s.out_buf = 0; s.ubias_off = -1; P.push_back(s); }
-    int Hp = total;                       // halo the NEXT coupling's input half still needs
-    const int wnL = M.cp[0].wn.n, wnH = M.cp[0].wn.H;
-    for (int i = M.n_flows - 1; i >= 0; i--) {
-        const DCoupling& cp = M.cp[i];
-        const DWn& w = cp.wn;
-        Hp -= R[i];                       // halo of this coupling's own output (x1 - m)
-        const int x0row = cp.flipped ? half : 0, dstrow = cp.flipped ? 0 : half;
-        P.push_back(conv_step(cp.pre, Hp + R[i], EPI_STORE, 0, x0row, 1, 0));
-        int a = Hp + R[i];
-        for (int l = 0; l < w.n; l++) {
-            a -= w.in[l].dil * (w.in[l].k - 1) / 2;
-            PkStep g = conv_step(w.in[l], a, EPI_GATE, 1, 0, 2, 0);
-            g.H = w.H;
-            if (w.has_cond) g.ubias_off = i * ((2 * wnH * wnL + 3) & ~3) + l * 2 * w.H;      // 16-byte aligned blocks (cf. run())
-            P.push_back(g);
-            PkStep r = conv_step(w.rs[l], a, EPI_RESSKIP, 2, 0, 1, 0);
-            r.H = w.H; r.epi_flag = l == 0 ? 1 : 0;
-            P.push_back(r);
-        }
-        P.push_back(conv_step(cp.post, Hp, EPI_SUB, 3, 0, 0, dstrow));
-    }
-    { PkStep s; memset(&s, 0, sizeof(s)); s.kind = PK_STORE_OUT; s.halo = 0; s.in_buf = 0; s.ubias_off = -1; P.push_back(s); }
-    if ((int)P.size() > PK_MAX_STEPS || Hp != 0) return false;
-    if (hipMalloc((void**)&pk_prog_, P.size() * sizeof(PkStep)) != hipSuccess) { pk_prog_ = nullptr; return false; }
-    if (hipMalloc((void**)&pk_ctr_, pk_counter_bytes()) != hipSuccess) { pk_ctr_ = nullptr; return false; }
-    if (hipMemcpy(pk_prog_, P.data(), P.size() * sizeof(PkStep), hipMemcpyHostToDevice) != hipSuccess) return false;
-    if (hipMemset(pk_ctr_, 0, pk_counter_bytes()) != hipSuccess) return false;
-    pk_nsteps_ = (int)P.size(); pk_halo_ = total;
-    pk_state_ = 1;
-    return true;
-}
-#endif  // STS_EXPERIMENTS
 
 void Engine::tap(const char* name, const float* d, int channels, long ld, long length) {
     if (!record_taps) return;
@@ -421,7 +339,7 @@ struct BufT {
     float *g, *cond_dp, *cond_dec, *cond_wn;
 };
 struct BufF {
-    float *z, *h, *acts, *out, *x0, *regA, *regB, *tailA, *tailB, *tailC, *wave, *fliptmp, *pk; long long* pk_trace;
+    float *z, *h, *acts, *out, *x0, *regA, *regB, *tailA, *tailB, *tailC, *wave, *fliptmp;
     float *ff_h[2], *ff_part[2], *ff_macc[2], *ff_alt;        // one-launch-per-layer flow (wn_flow.hip): channel-minor h / partial sums / -m slices, alternate home of a z half
     int16_t* pcm;
 };
@@ -444,9 +362,8 @@ struct Engine::RunCtx {
     // Fld = the count rounded up to a bucket of 64 frames, so that a call which launches the flow and the decoder AHEAD of the frame count
     // (ahead: the count is predicted, the kernels read the real one from device memory) makes exactly the dispatch decisions of a call
     // that waited for it -- and returns bit-identical samples.  Batches: Fld == Ftot, nothing changes.
-    long Fld = 0; int maxFld = 0; bool ahead = false, mapped = false;
+    long Fld = 0; int maxFld = 0; bool ahead = false, mapped = false, forced = false; unsigned long long req_key = 0;
     int halo = 0; long Wcap = 0; int upS = 1; long Lsb = 0; int sbC = 0;
-    bool use_pk = false; int pk_fs = 0, pk_wld = 0, pk_rows = 0;
     bool use_ff = false; int ffG = 0;
 };
 #define RUN_ALIASES(c)                                                                                                              \
@@ -465,8 +382,7 @@ struct Engine::RunCtx {
     [[maybe_unused]] const long Fld = (c).Fld; [[maybe_unused]] const int maxFld = (c).maxFld; [[maybe_unused]] const bool ahead = (c).ahead; \
     [[maybe_unused]] const int halo = (c).halo; [[maybe_unused]] const long Wcap = (c).Wcap, Lsb = (c).Lsb;                         \
     [[maybe_unused]] const int upS = (c).upS, sbC = (c).sbC;                                                                        \
-    [[maybe_unused]] const bool use_ff = (c).use_ff; [[maybe_unused]] const int ffG = (c).ffG;                                      \
-    [[maybe_unused]] const bool use_pk = (c).use_pk; [[maybe_unused]] const int pk_fs = (c).pk_fs, pk_wld = (c).pk_wld, pk_rows = (c).pk_rows;
+    [[maybe_unused]] const bool use_ff = (c).use_ff; [[maybe_unused]] const int ffG = (c).ffG;
 
 // ---- stage 0: batch geometry at the phoneme level, phoneme-level workspace, the one host-to-device copy of a run
 int Engine::run_setup(RunCtx& c) {
@@ -708,20 +624,36 @@ int Engine::run_durations(RunCtx& c) {
     }
     const bool mapped = c.mapped = !no_mapped && hmap_ && arrive_;
     if (mapped) { seq_ = seq_ == 0x7fffffff ? 1 : seq_ + 1; }
-    // Launch-ahead (one utterance, plain call): the flow and the decoder are enqueued for a PREDICTED frame capacity -- the largest count
-    // an utterance of this many phonemes has produced on this engine, in buckets of 64 frames -- and read the real count from device
-    // memory, where the durations kernel leaves it (clamped to the capacity).  The host never waits between the duration predictor and the
-    // flow; it reads the count after the last kernel is enqueued, sizes the PCM download with it, and repeats flow + decoder the
-    // waiting way in the rare case that the count exceeded the capacity.
+    // Launch-ahead (one utterance, plain call): the flow and the decoder are enqueued for a PREDICTED frame capacity and read the real
+    // count from device memory, where the durations kernel leaves it (clamped to the capacity).  The host never waits between the duration
+    // predictor and the flow; it reads the count after the last kernel is enqueued and sizes the PCM download with it.
+    // The prediction is a MEMO, not a guess (round 5): the reference's noise scale is hard-coded 0 (SynthesizerTrn.cpp:357), so the
+    // frame count is a pure function of (phoneme ids, speaker, length scale); the engine remembers the count of its last 64 distinct
+    // requests under a 64-bit hash of exactly those inputs.  A request it has seen runs ahead with the exact count -- never more than the
+    // 63 frames of bucket padding the waiting path also carries, never a miss; any other request takes the waiting path.  Should the
+    // count land in another 64-frame bucket than predicted (a hash collision), the two stages are repeated the waiting way, so the samples a
+    // request returns never depend on what the engine served before (dispatch decisions are taken per bucket).
     long pred = 0;
+    c.req_key = 0;
+    if (B == 1) {
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&h](unsigned v) { for (int q = 0; q < 4; q++) { h ^= (v >> (8 * q)) & 0xffu; h *= 1099511628211ull; } };
+        mix((unsigned)Ttot);
+        if (launch_ahead != 2) {          // (2: test mode -- the key is the phoneme count alone, i.e. every request of a length collides)
+            mix((unsigned)c.sid[0]); { unsigned u; memcpy(&u, &c.ls[0], 4); mix(u); }
+            for (long t = 0; t < Ttot; t++) mix((unsigned)c.ids[0][t]);
+        }
+        c.req_key = h | 1ull;
+    }
     if (launch_ahead && B == 1 && !ss && !have_forced && !record_taps && mapped)
-        for (const auto& tf : seen_tf_) if (tf.first == (int)Ttot && tf.second > pred) pred = tf.second;
+        for (const auto& tf : seen_tf_) if (tf.first == c.req_key) pred = tf.second;
     c.ahead = pred > 0;
     c.hop = M.hop_total;
     const long cap = c.ahead ? (pred + 63) / 64 * 64 : 0;
     durations(r_final, M.dur_type == 0 ? 1 : 0, M.ea_m, M.ea_logs, bt.ls, have_forced ? bt.forced : nullptr, bt.dlogw,
               bt.dur, bt.cum, bt.frames, lvT.seg, B, stream, mapped ? hmap_dev_ : nullptr, Ttot, seq_, arrive_,
               c.ahead ? c.d_lenF : nullptr, c.ahead ? c.d_win + 2 : nullptr, (int)cap);
+    c.forced = have_forced;
     have_forced = false;
     mark(2);
     sync_wait_ms_ = 0;
@@ -776,10 +708,10 @@ int Engine::wait_frame_counts(RunCtx& c) {
         int f = p_down[Ttot + b];
         p_offF[b] = (int)c.Ftot; p_lenF[b] = f; c.Ftot += f; if (f > c.maxF) c.maxF = f;
     }
-    if (B == 1) {      // what an utterance of this length needs: the launch-ahead capacity of later calls
+    if (B == 1 && c.req_key && !c.forced) {      // the memo of run_durations: this request's frame count (replaces, never a running maximum)
         bool found = false;
-        for (auto& tf : seen_tf_) if (tf.first == (int)Ttot) { if (c.Ftot > tf.second) tf.second = c.Ftot; found = true; }
-        if (!found) { if (seen_tf_.size() >= 64) seen_tf_.erase(seen_tf_.begin()); seen_tf_.emplace_back((int)Ttot, c.Ftot); }
+        for (auto& tf : seen_tf_) if (tf.first == c.req_key) { tf.second = c.Ftot; found = true; }
+        if (!found) { if (seen_tf_.size() >= 64) seen_tf_.erase(seen_tf_.begin()); seen_tf_.emplace_back(c.req_key, c.Ftot); }
     }
     return STS_OK;
 }
@@ -834,22 +766,8 @@ int Engine::run_frame_workspace(RunCtx& c) {
           if (i & 1) { if (stage_elems[i] > regB) regB = stage_elems[i]; } else { if (stage_elems[i] > regA) regA = stage_elems[i]; } } }
     const long Lsb = c.Lsb = Wcap * upS + B;           // MB-iSTFT: frames + 1 per window
     const int sbC = c.sbC = M.conv_post.Cout;
-    // one utterance: the whole flow as ONE persistent launch, the frame axis cut into one window per XCD (persist.hip).  Measured on
-    // MI355X (profiles/r03_pk_flow_trace.log): correct and deadlock-free, but at 128 phonemes it takes 0.50 ms against
-    // 0.44 ms for the 41 launches -- an op inside the persistent kernel still costs ~6 us of dependent latencies (claim, operand
-    // round trips, partial-sum exchange, store acknowledgement, completion poll) and the gate convs are fp32-MFMA-bound on windows
-    // that overlap 1.77x -- so the launch-per-layer path stays the default and this one is opt-in: front_mode 2 (sts_debug_set)
-#ifdef STS_EXPERIMENTS
-    const bool use_pk = c.use_pk = B == 1 && !c.ahead && !M.cp.empty() && front_mode == 2 && conv_mode == 0 && conv_math != 2 && c.Ftot <= 16384 && flow_program();
-    const int pk_fs = c.pk_fs = (int)((c.Ftot + 7) / 8);
-    const int pk_wld = c.pk_wld = (pk_fs + 2 * pk_halo_ + 31) / 32 * 32 + 32;
-    const int pk_rows = c.pk_rows = C > wnH ? C : wnH;
-#else
-    const bool use_pk = c.use_pk = false;       // (the shipped library carries no persistent flow kernel)
-    const int pk_fs = 0, pk_wld = 0, pk_rows = 0;
-#endif
     // the reverse flow as one launch per WaveNet layer (wn_flow.hip): every coupling must carry the fused operands, with one geometry
-    bool use_ff = flow_fused && !use_pk && conv_mode == 0 && conv_math == 3 && !M.cp.empty() && wnH > 0;
+    bool use_ff = flow_fused && conv_mode == 0 && conv_math == 3 && !M.cp.empty() && wnH > 0;
     for (size_t i = 0; i < M.cp.size() && use_ff; i++)
         use_ff = M.cp[i].ff.ok && M.cp[i].wn.H == wnH && M.cp[i].wn.n == c.wnL && M.cp[i].ff.G == M.cp[0].ff.G && M.cp[i].wn.in[0].k == M.cp[0].wn.in[0].k;
     if (use_ff) {
@@ -870,10 +788,6 @@ int Engine::run_frame_workspace(RunCtx& c) {
             bf.ff_macc[q] = A.get<float>(use_ff ? (size_t)c.ffG * (C / 2) * Ftot : 1);
         }
         bf.ff_alt = A.get<float>(use_ff ? (size_t)C * Ftot : 1);
-#ifdef STS_EXPERIMENTS
-        bf.pk = A.get<float>(use_pk ? (size_t)8 * 4 * pk_rows * pk_wld : 1);
-        bf.pk_trace = A.get<long long>(use_pk && pk_trace ? (size_t)256 * PK_MAX_STEPS * 8 : 1);
-#endif
         bf.z = A.get<float>((size_t)C * Ftot); bf.h = A.get<float>((size_t)wnH * Ftot);
         bf.acts = A.get<float>((size_t)wnH * Ftot); bf.out = A.get<float>((size_t)wnH * Ftot);
         bf.fliptmp = A.get<float>((M.n_flows & 1) ? (size_t)C * Ftot : 1);
@@ -900,7 +814,6 @@ int Engine::run_frame_workspace(RunCtx& c) {
     Lvl& lv1 = c.lv1; lv1 = Lvl(); lv1.seg = (inl && !c.ahead) ? SegView{nullptr, nullptr, 1, 0, 0, p_lenF[0]} : SegView{d_offF, d_lenF, 1, 0, 0, 0};
     lv1.nb = B; lv1.max_len = maxF; lv1.total = Ftot; lv1.ld = Ftot;
     mark(7);
-    (void)pk_fs; (void)pk_wld; (void)pk_rows;
     return STS_OK;
 }
 
@@ -982,58 +895,6 @@ int Engine::run_flow(RunCtx& c) {
         if (pend_set >= 0) finish_half(pend_half, pend_set);
         for (int hh = 0; hh < 2; hh++) if (cur[hh] != home[hh]) finish_half(hh, -1);
     } else
-#ifdef STS_EXPERIMENTS
-    if (use_pk) {
-        if (record_taps) { expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream); tap("z_p", bf.z, C, Ftot, Fcount); }
-        const long cstride = (long)((2 * wnH * wnL + 3) & ~3);
-        for (int i = M.n_flows - 1; i >= 0; i--) {        // speaker conditioning of every coupling up front + the stage's FLOP / byte account
-            const DCoupling& cp = M.cp[i];
-            const DWn& w = cp.wn;
-            if (w.has_cond) conv(w.cond, bt.g, lvB, bt.cond_wn + (size_t)i * cstride, lvB, ConvOpt());
-            (void)conv_args(cp.pre, nullptr, lv1, nullptr, lv1, ConvOpt(), nullptr);
-            for (int l = 0; l < w.n; l++) {
-                ConvOpt og; og.epi = EPI_GATE;
-                (void)conv_args(w.in[l], nullptr, lv1, nullptr, lv1, og, nullptr);
-                ConvOpt orr; orr.epi = EPI_RESSKIP;
-                (void)conv_args(w.rs[l], nullptr, lv1, nullptr, lv1, orr, nullptr);
-            }
-            ConvOpt os; os.epi = EPI_SUB;
-            (void)conv_args(cp.post, nullptr, lv1, nullptr, lv1, os, nullptr);
-        }
-        PkFlowArgs P;
-        memset(&P, 0, sizeof(P));
-        P.prog = pk_prog_; P.nsteps = pk_nsteps_;
-        P.m = bt.m; P.m_ld = Ttot; P.cum = bt.cum; P.T = (int)Ttot;
-        P.z = bf.z; P.z_ld = Ftot; P.F = (int)Fcount; P.C = C;
-        P.priv = bf.pk; P.priv_stride = (long)4 * pk_rows * pk_wld; P.wld = pk_wld; P.rows = pk_rows;
-        P.fs = pk_fs; P.halo_total = pk_halo_;
-        P.cond = bt.cond_wn; P.ctr = pk_ctr_;
-        if (pk_trace) { (void)hipMemsetAsync(bf.pk_trace, 0, (size_t)256 * PK_MAX_STEPS * 8 * sizeof(long long), stream); P.trace = bf.pk_trace; }
-        pk_flow(P, stream);
-        if (pk_trace) {     // debugging aid: [256][PK_MAX_STEPS][4] ticks relative to the earliest stamp, as floats
-            std::vector<long long> h((size_t)256 * PK_MAX_STEPS * 8);
-            (void)hipStreamSynchronize(stream);
-            (void)hipMemcpy(h.data(), bf.pk_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-            // every XCD has its own counter: stamps are made relative to the earliest stamp of the workgroup's XCD
-            long long t0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            std::vector<int> xcd(256, -1);
-            for (int wg = 0; wg < 256; wg++)
-                for (int s2 = 0; s2 < PK_MAX_STEPS && xcd[wg] < 0; s2++) { const long long v = h[((size_t)wg * PK_MAX_STEPS + s2) * 8 + 3]; if (v > 0) xcd[wg] = (int)(v / 1000) & 7; }
-            for (int wg = 0; wg < 256; wg++) if (xcd[wg] >= 0)
-                for (int s2 = 0; s2 < PK_MAX_STEPS; s2++) for (int q = 0; q < 8; q++) {
-                    const long long v = h[((size_t)wg * PK_MAX_STEPS + s2) * 8 + q];
-                    if (q != 3 && v && (!t0[xcd[wg]] || v < t0[xcd[wg]])) t0[xcd[wg]] = v;
-                }
-            Tap& t = taps["pk_trace"];
-            t.channels = 256 * 8; t.length = PK_MAX_STEPS;
-            t.data.assign((size_t)256 * 8 * PK_MAX_STEPS, -1.f);
-            for (int wg = 0; wg < 256; wg++) if (xcd[wg] >= 0) for (int s2 = 0; s2 < PK_MAX_STEPS; s2++) for (int q = 0; q < 8; q++) {
-                const long long v = h[((size_t)wg * PK_MAX_STEPS + s2) * 8 + q];
-                t.data[((size_t)wg * 8 + q) * PK_MAX_STEPS + s2] = q == 3 ? (float)v : (v ? (float)(v - t0[xcd[wg]]) : -1.f);
-            }
-        }
-    } else
-#endif
     {
     expand_frames(bt.m, Ttot, bt.cum, lvT.seg, lv1.seg, C, bf.z, Ftot, B, maxF, stream);
     tap("z_p", bf.z, C, Ftot, Fcount);
@@ -1066,128 +927,6 @@ int Engine::run_flow(RunCtx& c) {
 #undef maxF
 }
 
-#ifdef STS_EXPERIMENTS   // lab build only: a tie with the grouped launches
-// One decoder stage of one utterance as ONE persistent launch (conv_bf3_stage, kernels.hpp StageArgs): the time axis cut into a
-// window per XCD (own column tiles + one tile of halo per side), private per-XCD buffers for the chain intermediates, the stage's
-// final chain outputs written (own columns only) where the grouped launches would have put them.  Returns false when the stage is
-// not eligible -- the caller then issues the grouped launches.  /root/reference/src/modules/ResBlock1.cpp:55-69.
-bool Engine::stage_persistent(RunCtx& c, int i, const float* bup, const Lvl& l2, float* reg, size_t ce, const float** outs) {
-    (void)c;
-    Model& M = model;
-    const int nk = M.n_resk;
-    const int nd = nk > 0 ? (int)M.rb[(size_t)i * nk].c1.size() : 0;
-    const int Cst = M.ups[i].Cout;
-    if (l2.nb != 1 || nk < 1 || nk > kMaxGroup || nd < 1 || Cst != 128) return false;
-    for (int j = 0; j < nk; j++) {       // one 128-column tile of halo per side must cover the receptive field of the whole chain
-        const DResBlock& rb = M.rb[(size_t)i * nk + j];
-        int r = 0;
-        for (int d = 0; d < nd; d++) r += rb.c1[d].dil * (rb.c1[d].k - 1) / 2 + rb.c2[d].dil * (rb.c2[d].k - 1) / 2;
-        if (r > 128 || (int)rb.c2.size() != nd) return false;
-    }
-    const long L = l2.total;
-    const int ntile = (int)((L + 127) / 128);
-    if (ntile < 8 * 3 || ntile / 8 + 3 > PS_MAX_COLS) return false;
-    const int nops = 2 * nd;
-    if (nops * nk > 32) return false;      // PS_MAX_CONVS: descriptors of a stage kept in the kernel's LDS
-    if (ps_tab_busy_) { (void)hipStreamSynchronize(stream); ps_tab_busy_ = false; }     // an earlier stage of this run still owns the staging table
-    // windows: XCD x owns column tiles [t0, t1), computes [t0 - 1, t1 + 1) clipped
-    int own0[8], own1[8], win0[8], win1[8], ncol[8], maxw = 0;
-    for (int x = 0; x < 8; x++) {
-        own0[x] = (int)((long)ntile * x / 8); own1[x] = (int)((long)ntile * (x + 1) / 8);
-        win0[x] = own0[x] > 0 ? own0[x] - 1 : 0; win1[x] = own1[x] < ntile ? own1[x] + 1 : ntile;
-        ncol[x] = win1[x] - win0[x];
-        if (ncol[x] > maxw) maxw = ncol[x];
-    }
-    const long Wx = (long)maxw * 128;
-    const size_t need = (size_t)8 * nk * 3 * Cst * Wx;
-    if (need > ps_priv_cap_) {
-        (void)hipStreamSynchronize(stream);
-        if (ps_priv_) (void)hipFree(ps_priv_);
-        ps_priv_ = nullptr; ps_priv_cap_ = 0;
-        if (hipMalloc((void**)&ps_priv_, (need + need / 8) * sizeof(float)) != hipSuccess) return false;
-        ps_priv_cap_ = need + need / 8;
-    }
-    const size_t ntab = (size_t)8 * nops * nk;
-    if (ntab > ps_tab_cap_) {
-        (void)hipStreamSynchronize(stream);
-        if (ps_tab_) (void)hipFree(ps_tab_);
-        if (ps_tab_host_) (void)hipHostFree(ps_tab_host_);
-        ps_tab_ = nullptr; ps_tab_host_ = nullptr; ps_tab_cap_ = 0;
-        if (hipMalloc((void**)&ps_tab_, ntab * sizeof(ConvArgs)) != hipSuccess) return false;
-        if (hipHostMalloc((void**)&ps_tab_host_, ntab * sizeof(ConvArgs), hipHostMallocDefault) != hipSuccess) return false;
-        ps_tab_cap_ = ntab;
-    }
-    const size_t cb = ps_counter_bytes(nops, nk);
-    if (cb > ps_ctr_cap_) {
-        (void)hipStreamSynchronize(stream);
-        if (ps_ctr_) (void)hipFree(ps_ctr_);
-        ps_ctr_ = nullptr; ps_ctr_cap_ = 0;
-        if (hipMalloc((void**)&ps_ctr_, cb) != hipSuccess) return false;
-        if (hipMemset(ps_ctr_, 0, cb) != hipSuccess) return false;
-        ps_ctr_cap_ = cb;
-    }
-    // members ordered longest K first (as the grouped launches order them)
-    int order[kMaxGroup];
-    for (int j = 0; j < nk; j++) order[j] = j;
-    for (int a2 = 1; a2 < nk; a2++)
-        for (int b2 = a2; b2 > 0 && M.rb[(size_t)i * nk + order[b2]].c1[0].k > M.rb[(size_t)i * nk + order[b2 - 1]].c1[0].k; b2--) { const int t = order[b2]; order[b2] = order[b2 - 1]; order[b2 - 1] = t; }
-    const double f0 = flops_[3], b0 = bytes_[3];
-    bool ok = true;
-    for (int x = 0; x < 8 && ok; x++) {
-        const long wlo = (long)win0[x] * 128, whi = std::min<long>(L, (long)win1[x] * 128);
-        const int Wlen = (int)(whi - wlo);
-        Lvl lw; lw.seg = SegView{nullptr, nullptr, 1, 0, 0, Wlen}; lw.nb = 1; lw.max_len = Wlen; lw.total = Wlen; lw.ld = Wx;     // private window
-        Lvl ls = lw; ls.ld = l2.ld;                                                                                           // window of a shared buffer
-        for (int mi = 0; mi < nk && ok; mi++) {
-            const int j = order[mi];
-            const DResBlock& rb = M.rb[(size_t)i * nk + j];
-            float* pt1 = ps_priv_ + ((size_t)(x * nk + j) * 3 + 0) * Cst * Wx;
-            float* ppa = pt1 + (size_t)Cst * Wx, *ppb = ppa + (size_t)Cst * Wx;
-            float* shared_out = reg + (size_t)(1 + 3 * j) * ce + ce;          // where the grouped path leaves chain j's result when nd is odd/even: see below
-            const float* cur = bup + wlo; bool cur_shared = true;
-            float* nxt_priv = ppa;
-            for (int d = 0; d < nd && ok; d++) {
-                const bool last = d + 1 == nd;
-                ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
-                ConvArgs a1 = conv_args(rb.c1[d], cur, cur_shared ? ls : lw, pt1, lw, o1, nullptr);
-                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur; o2.epi = EPI_RESADD; o2.res_ld = cur_shared ? l2.ld : Wx;
-                float* dst = last ? (shared_out + wlo) : nxt_priv;
-                ConvArgs a2 = conv_args(rb.c2[d], pt1, lw, dst, last ? ls : lw, o2, nullptr);
-                if (last) { a2.keep_lo = (int)((long)own0[x] * 128 - wlo); a2.keep_hi = (int)(std::min<long>(L, (long)own1[x] * 128) - wlo); }
-                ok = conv_bf3_stage_eligible(a1) && conv_bf3_stage_eligible(a2);
-                ps_tab_host_[((size_t)x * nops + 2 * d) * nk + mi] = a1;
-                ps_tab_host_[((size_t)x * nops + 2 * d + 1) * nk + mi] = a2;
-                cur = nxt_priv; cur_shared = false;
-                nxt_priv = nxt_priv == ppa ? ppb : ppa;
-            }
-            outs[j] = shared_out;
-        }
-    }
-    flops_[3] = f0; bytes_[3] = b0;        // (the table's conv_args calls booked 8 windows: undone; the stage is booked once below)
-    if (!ok) return false;
-    {   // FLOPs / algorithmic bytes exactly as the grouped launches book them
-        double fl = 0, f = 0;
-        for (int j = 0; j < nk; j++) {
-            const DResBlock& rb = M.rb[(size_t)i * nk + j];
-            for (int d = 0; d < nd; d++) {
-                ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
-                (void)conv_args(rb.c1[d], bup, l2, reg, l2, o1, &f); fl += f;
-                ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = bup; o2.epi = EPI_RESADD;
-                (void)conv_args(rb.c2[d], bup, l2, reg, l2, o2, &f); fl += f;
-            }
-        }
-        mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_ += 1;
-    }
-    if (hipMemcpyAsync(ps_tab_, ps_tab_host_, ntab * sizeof(ConvArgs), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
-    StageArgs A;
-    memset(&A, 0, sizeof(A));
-    A.tab = ps_tab_; A.nops = nops; A.nmem = nk; A.ctr = ps_ctr_;
-    for (int x = 0; x < 8; x++) A.ncol[x] = ncol[x];
-    conv_bf3_stage(A, stream);
-    ps_tab_busy_ = true;
-    return true;
-}
-#endif  // STS_EXPERIMENTS
 
 // ---- stage 5: one decode pass over `nw` windows of z
 // ---------------- decoder trunk (Generator_hifigan.cpp:139-175 and the identical loops of MS/Istft/MBB)
@@ -1253,11 +992,6 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             flops_[3] = f0; bytes_[3] = b0;
             grouped = conv_group_eligible(G);
         }
-#ifdef STS_EXPERIMENTS
-        if (grouped && trunk_mode == 2 && conv_math == 0 && nw == 1 && stage_persistent(c, i, bup, l2, reg, ce, outs)) {
-            // (the whole stage went out as one persistent launch)
-        } else
-#endif
         if (grouped) {
             // Layer d of ALL chains goes out as one grouped launch: 2 * nd launches per stage instead of
             // 2 * nd * nResK, nResK times the workgroups per launch (a batch-1 stage otherwise yields only a
@@ -1524,9 +1258,6 @@ int Engine::run_once(int B, const int32_t* const* ids, const int32_t* n, const i
     for (double& f : bytes_) f = 0;
     for (double& f : bytes_w_) f = 0;
     mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
-#ifdef STS_EXPERIMENTS
-    ps_tab_busy_ = false;          // (the previous run ended with a stream synchronisation)
-#endif
 
     host_t0_ = now_us(); host_t_sync_ = 0;
     RunCtx c;
@@ -1558,9 +1289,9 @@ int Engine::run_output(RunCtx& c) {
             HIPCK(hipStreamSynchronize(stream));
             host_t_sync_ = now_us();
             if ((rc = wait_frame_counts(c)) != STS_OK) return rc;
-            if (c.Ftot > Fld) {
-                // more frames than the capacity this call was launched for (an utterance of this length had never needed as many): the
-                // kernels clamped to the capacity, their output is discarded, and flow + decoder run again the waiting way
+            if ((c.Ftot + 63) / 64 * 64 != Fld) {
+                // the count is not in the bucket this call was launched for (possible only when two requests share a hash): the output is
+                // discarded, and flow + decoder run again the waiting way -- what a request returns does not depend on the engine's history
                 ahead_misses++;
                 HIPCK(hipStreamSynchronize(stream));
                 c.ahead = false;

@@ -63,7 +63,10 @@ public:
     // results of the last run
     std::vector<int32_t> n_samples;    // per utterance
     int64_t total_samples = 0;
-    int16_t* d_pcm = nullptr;          // device, packed
+    int16_t* d_pcm = nullptr;          // device, packed (the mapped pinned HOST buffer when pcm_in_host_: use pcm_hbm() where a true device buffer is required)
+    // the last run's PCM in HBM, or null when no HBM copy exists (pcm_in_host_: the kernels wrote it over the host link) -- what RCCL
+    // transfers and device-to-device copies must use (xGMI / D2D traffic out of host memory by accident)
+    const int16_t* pcm_hbm() const { return pcm_in_host_ ? nullptr : d_pcm; }
     float host_us_setup_ = 0, host_us_enq_ = 0;
     double host_t0_ = 0, host_t_sync_ = 0;   // steady-clock microseconds: entry of the run, return of its last stream synchronisation
     bool pcm_in_host_ = false;         // this run's PCM was written by the kernels into the pinned host buffer (d_pcm is its device-side address; no HBM copy exists)
@@ -84,16 +87,11 @@ public:
     int dds_tail = 1;                  // 1: a ConvFlow's 29-row projection and spline step ride in its last DDSConv layer's launch (col_layer.hip tail) (STS_DBG_DDS_TAIL)
     int attn_reg = 1;                  // 1: one-query attention with its operands in registers (attention_reg_kernel) where the shape allows (STS_DBG_ATTN_REG)
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
-    int launch_ahead = 1;              // 1: a one-utterance call enqueues flow + decoder before the frame count is on the host (sts_debug_set STS_DBG_LAUNCH_AHEAD)
-    long ahead_misses = 0;             // launch-ahead calls whose capacity was too small (repeated the waiting way)
-    std::vector<std::pair<int, long>> seen_tf_;    // (phonemes, most frames such an utterance produced on this engine): the launch-ahead capacity
+    int launch_ahead = 1;              // 1: a one-utterance call the engine has served before enqueues flow + decoder before the frame count is on the host; 2 (tests): the memo is keyed by the phoneme count alone (sts_debug_set STS_DBG_LAUNCH_AHEAD)
+    long ahead_misses = 0;             // launch-ahead calls whose count fell outside the predicted 64-frame bucket (a hash collision; repeated the waiting way)
+    std::vector<std::pair<unsigned long long, long>> seen_tf_;    // (hash of a one-utterance request's ids / speaker / length scale, its frame count): the launch-ahead memo, 64 entries FIFO
     int flow_fused = 1;                // 1: the reverse flow as one launch per WaveNet layer where eligible (wn_flow.hip; two-term fp16 arithmetic only);
                                        // 0: one launch per conv (sts_debug_set STS_DBG_FLOW_FUSED)
-#ifdef STS_EXPERIMENTS                 // lab build only (`make exp`): the two persistent-kernel families that lost their A/B
-    bool pk_trace = false;             // record the persistent kernel's per-op timeline into taps["pk_trace"] (sts_debug_set)
-    int trunk_mode = 0;                // 0 automatic (today: grouped launches), 1 grouped launches, 2 persistent stage kernel where eligible (sts_debug_set)
-    int front_mode = 0;                // 0 automatic, 1 one launch per layer, 2 persistent single-XCD kernel wherever eligible (sts_debug_set)
-#endif
     hipStream_t stream = nullptr;
 
 private:
@@ -118,9 +116,6 @@ private:
     int wait_frame_counts(RunCtx& c);
     int frame_geometry(RunCtx& c);
     int run_output(RunCtx& c);
-#ifdef STS_EXPERIMENTS
-    bool flow_program();            // builds (once) the op program of the persistent single-launch flow (persist.hip); false: not eligible
-#endif
     void tap(const char* name, const float* d, int channels, long ld, long length);
     void stage_begin(int s);
     void mark(int i);
@@ -133,13 +128,6 @@ private:
     unsigned* ovf_host_ = nullptr; unsigned* ovf_ = nullptr;              // conv_math 3: overflow word (host-mapped) and its device address
     int* hmap_ = nullptr; int* hmap_dev_ = nullptr; size_t hmap_cap_ = 0;   // host-mapped result block of the durations kernel
     unsigned* arrive_ = nullptr; int seq_ = 0;
-#ifdef STS_EXPERIMENTS
-    // persistent decoder-stage kernel (conv_bf3_stage): per-XCD private stage buffers, the conv table and its counters
-    float* ps_priv_ = nullptr; size_t ps_priv_cap_ = 0; ConvArgs* ps_tab_ = nullptr; ConvArgs* ps_tab_host_ = nullptr; size_t ps_tab_cap_ = 0;
-    unsigned* ps_ctr_ = nullptr; size_t ps_ctr_cap_ = 0; bool ps_tab_busy_ = false;
-    bool stage_persistent(RunCtx& c, int stage, const float* bup, const Lvl& l2, float* reg, size_t ce, const float** outs);
-    PkStep* pk_prog_ = nullptr; int pk_nsteps_ = 0, pk_halo_ = 0, pk_state_ = 0; unsigned* pk_ctr_ = nullptr;   // persistent flow kernel
-#endif
     hipEvent_t ev_[8] = {};
     static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently
     hipStream_t aux_[kAux] = {};

@@ -154,50 +154,6 @@ struct AttnArgs {
     int attn_reg;                   // 1: the one-query kernel with its operands in registers where the shape allows (attention_reg_kernel)
 };
 
-#ifdef STS_EXPERIMENTS   // lab build only (`make exp`): persistent-kernel families that lost their A/B against the launch path
-// ---- persistent single-launch flow (persist.hip): the reverse flow of ONE utterance, frame axis cut into 8 windows (one per XCD),
-// every window processed by the workgroups of its XCD with L2-local barriers between the ops
-constexpr int PK_MAX_STEPS = 96;
-enum PkKind : int { PK_EXPAND = 0, PK_CONV = 1, PK_STORE_OUT = 2 };
-struct PkStep {
-    int kind;
-    int halo;                       // the op's output is needed on the frames an XCD owns +- halo
-    const float* w; const float* bias;      // packed weights [ntap][Cin_pad][Cout_pad] / bias [Cout_pad] (model storage)
-    int ubias_off;                  // per-utterance bias (speaker conditioning): float offset into PkFlowArgs::cond, < 0: none
-    int Cin, Cout, Cin_pad, Cout_pad, ntap, tap_step, tap_off;
-    int epi, epi_flag, H, gate_perm;
-    int in_buf, in_row, out_buf, out_row, aux_buf;      // private buffers 0..3 (z, h, acts, out) and first row inside them
-};
-struct PkFlowArgs {
-    const PkStep* prog; int nsteps;
-    const float* m; long m_ld; const int* cum; int T;   // length regulator source: m [C][m_ld], cum[T] = inclusive prefix of the durations
-    float* z; long z_ld; int F; int C;                  // shared output z [C][z_ld], F frames
-    float* priv; long priv_stride; int wld, rows;       // per XCD: 4 buffers of [rows][wld] floats, priv_stride floats apart
-    int fs, halo_total;                                 // frames owned per XCD, receptive field of the whole flow (per side)
-    const float* cond;                                  // base of the per-utterance biases
-    unsigned* ctr;                                      // pk_counter_bytes() of zeroed device memory (re-armed by the kernel itself)
-    long long* trace;                                   // optional [256 workgroups][PK_MAX_STEPS][8]: s_memtime at op start / chunk done / op complete, xcd * 1000 + chunk + 1, conv entry / K loop done / partials combined / stores complete
-};
-size_t pk_counter_bytes();
-void pk_flow(const PkFlowArgs& A, hipStream_t st);
-
-// ---- persistent decoder-stage kernel (conv_bf3.hip, round 3): the 2 x nd grouped ResBlock convs of ONE decoder stage of ONE utterance
-// in one launch.  The time axis is cut into one window per XCD (own column tiles + one tile of halo per side, recomputed); inside
-// an XCD workgroups claim (op, column tile, chain) items in dependency order and wait on the completion flags of the three column
-// tiles of the previous op they read -- tiles of consecutive layers overlap, the chains balance dynamically, nothing drains
-// between the convs.  tab[(xcd * nops + op) * nmem + m]: the conv of op `op`, chain m, on XCD xcd's window (pointers already
-// offset to the window; private per-XCD buffers for everything but the stage's input and its final outputs).
-constexpr int PS_MAX_COLS = 512;
-struct StageArgs {
-    const ConvArgs* tab;
-    int nops, nmem;
-    int ncol[8];                    // column tiles (of 128) of each XCD's window
-    unsigned* ctr;                  // ps_counter_bytes() of zeroed device memory; the kernel re-arms it
-};
-size_t ps_counter_bytes(int nops, int nmem);
-bool conv_bf3_stage_eligible(const ConvArgs& a);
-void conv_bf3_stage(const StageArgs& A, hipStream_t st);
-#endif  // STS_EXPERIMENTS
 
 // ---- one launch per WaveNet layer of the reverse flow (wn_flow.hip, round 4).  All intermediate tensors are CHANNEL-MINOR [frame][channel]
 // (packed frames as everywhere else); group g of G = H / Cg handles the gated channels [g Cg, (g + 1) Cg).

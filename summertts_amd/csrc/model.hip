@@ -223,27 +223,6 @@ bool pack_bf3(Store& st, DConv& d, bool perm_k = false) {
     return true;
 }
 
-#ifdef STS_EXPERIMENTS
-// copy of an already packed conv in the operand order of the persistent flow kernel (persist.hip): [tap][Cin_pad / 8][Cout_pad][8] --
-// the 8 input channels of a K group contiguous per output row, so that a lane fetches its four k values of a group with ONE
-// 16-byte load (lanes of the upper half-wave take channels 4..7)
-bool pack_k8(Store& st, DConv& d) {
-    if (d.depthwise || d.transposed || !d.w || d.Cin_pad % 8 != 0) return true;
-    const size_t n = (size_t)d.k * d.Cin_pad * d.Cout_pad;
-    float* p = st.alloc(n + 64, &d.wk8);
-    if (!p) return false;
-    const float* wh = st.host.data() + (d.w - st.dev);
-    for (int t = 0; t < d.k; t++)
-        for (int cb = 0; cb < d.Cin_pad / 8; cb++)
-            for (int r = 0; r < d.Cout_pad; r++)
-                for (int e = 0; e < 8; e++)
-                    p[(((size_t)t * (d.Cin_pad / 8) + cb) * d.Cout_pad + r) * 8 + e] = wh[((size_t)t * d.Cin_pad + cb * 8 + e) * d.Cout_pad + r];
-    return true;
-}
-#else
-bool pack_k8(Store&, DConv&) { return true; }     // (only the lab build's persistent flow kernel reads that copy)
-#endif
-
 // Operands of wn_flow.hip for one coupling (see DFlowFused).  post is linear, so m = post(sum_l skip_l) = sum_l (W_post W_skip_l) acts_l + const:
 // the composite matrices are formed in double here, negated (the kernel accumulates -m and ADDS it to x1), and appended to each layer's
 // res rows.  All sources are the already packed fp32 copies, so the coupling's channel reversal (folded into pre / post) is in.
@@ -556,7 +535,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         c.flipped = ((m.n_flows - i) & 1) != 0;
         HConv pre = parse_conv(r);
         if (!r.ok || pre.k != 1 || pre.in_ch != m.inter / 2) FAIL("coupling pre");
-        { PackOpts o; o.reverse_in = c.flipped; if (!pack_conv(st, pre, o, c.pre) || !pack_bf3(st, c.pre) || !pack_k8(st, c.pre)) FAIL("coupling pre pack"); }
+        { PackOpts o; o.reverse_in = c.flipped; if (!pack_conv(st, pre, o, c.pre) || !pack_bf3(st, c.pre)) FAIL("coupling pre pack"); }
         DWn& w = c.wn;
         w.n = r.geti(); const int wk = r.geti();
         if (!r.ok || w.n <= 0 || w.n > 64) FAIL("WN header");
@@ -569,13 +548,13 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
             if (h.in_ch != w.H || h.out_ch != 2 * w.H || h.k != wk) FAIL("WN in_layer shape");
             h.pad = (wk * dil - dil) / 2; h.dil = dil;
             PackOpts o; o.gate = true; o.gate_H = w.H;
-            if (!pack_conv(st, h, o, w.in[l]) || !pack_bf3(st, w.in[l]) || !pack_k8(st, w.in[l])) FAIL("WN in_layer pack");
+            if (!pack_conv(st, h, o, w.in[l]) || !pack_bf3(st, w.in[l])) FAIL("WN in_layer pack");
         }
         for (int l = 0; l < w.n; l++) {
             HConv h = parse_conv(r);
             if (!r.ok || h.k != 1 || h.in_ch != w.H || (h.out_ch != 2 * w.H && h.out_ch != w.H)) FAIL("WN res_skip");
             if ((l < w.n - 1) != (h.out_ch == 2 * w.H)) FAIL("WN res_skip shape");
-            if (!pack_conv(st, h, PackOpts(), w.rs[l]) || !pack_bf3(st, w.rs[l]) || !pack_k8(st, w.rs[l])) FAIL("WN res_skip pack");
+            if (!pack_conv(st, h, PackOpts(), w.rs[l]) || !pack_bf3(st, w.rs[l])) FAIL("WN res_skip pack");
             w.rs[l].H = w.H;
         }
         w.has_cond = m.is_ms == 1;
@@ -587,7 +566,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         }
         HConv post = parse_conv(r);
         if (!r.ok || post.k != 1 || post.out_ch != m.inter / 2 || post.in_ch != w.H || pre.out_ch != w.H) FAIL("coupling post");
-        { PackOpts o; o.reverse_out = c.flipped; if (!pack_conv(st, post, o, c.post) || !pack_bf3(st, c.post) || !pack_k8(st, c.post)) FAIL("coupling post pack"); }
+        { PackOpts o; o.reverse_out = c.flipped; if (!pack_conv(st, post, o, c.post) || !pack_bf3(st, c.post)) FAIL("coupling post pack"); }
         if (!pack_flow_fused(st, c)) FAIL("coupling fused-layer pack");
     }
 

@@ -33,7 +33,6 @@ struct DConv {
     const float* wc = nullptr;      // col_layer / col_proj A-strip copy of a 1x1 conv (DDSConv pointwise convs, attention o-proj, q/k/v, encoder proj)
     const float* bias_rows = nullptr;   // bias in source row order next to wc (== bias where the conv's rows are not permuted)
     const float* wu = nullptr;      // Winograd-domain copy [seg][4][Cin_pad][Cout_pad] (narrow decoder ResBlock convs)
-    const float* wk8 = nullptr;     // [tap][Cin_pad / 8][Cout_pad][8] copy for the persistent flow kernel (persist.hip)
     const void* wb3 = nullptr;      // split-bf16 copy (conv_bf3.hip: three bf16 planes, fragment order) of the decoder trunk convs
     const void* wb3p = nullptr;     // the same with the k order of resblock_bf3_kernel's parked intermediate (second conv of a narrow ResBlock layer)
     const void* wh2 = nullptr;      // two-term fp16 copy in wb3's layout (conv_bf3.hip MATH 1), weights scaled by 1 / h2_scale (a power of two)

@@ -105,15 +105,43 @@ struct sts_multi {
     bool rccl_broken = false;               // a collective failed or timed out: communicators aborted, downloads from the next call on
     static constexpr int kCollectiveTimeoutMs = 60000;
 
-    // all communicators of the handle go down together: a peer blocked in a collective returns with an error instead of hanging
+    // Who may touch comms[k] (round 5): every RCCL host call of rank k goes through rccl_call(k, ...), which takes the
+    // communicator under `mu`, marks the rank as inside a call, and refuses to start once the handle is broken.  abort_all() -- any rank's
+    // failure -- brings down, under the same lock, every communicator whose owner is NOT inside a host call (ranks parked in wait_stream:
+    // the aborted collective's kernel leaves their stream) and marks the others; an owner that was inside a call aborts its own
+    // communicator when the call returns.  So no thread ever passes an aborted (freed) or null communicator into RCCL.
+    std::vector<int> in_call; std::vector<char> abort_pending;
+    int gather_arrived = 0; int64_t gather_epoch = 0;       // host barrier in front of the gather (the collective timeout must not cover the peers' inference)
     void abort_all() {
         std::lock_guard<std::mutex> lk(mu);
         if (rccl_broken) return;
         rccl_broken = true;
         Rccl& R = rccl();
-        if (R.CommAbort) for (auto& c : comms) if (c) { (void)R.CommAbort(c); c = nullptr; }
+        for (size_t k = 0; k < comms.size(); k++) {
+            if (!comms[k]) continue;
+            if (in_call[k] > 0) { abort_pending[k] = 1; continue; }
+            if (R.CommAbort) (void)R.CommAbort(comms[k]);
+            comms[k] = nullptr;       // (without ncclCommAbort in the library the communicator is simply abandoned)
+        }
     }
     bool broken() { std::lock_guard<std::mutex> lk(mu); return rccl_broken; }
+    template <typename F> ncclResult_t rccl_call(int k, F&& f) {
+        ncclComm_t c;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rccl_broken || !comms[k]) return ncclInternalError;
+            in_call[k]++; c = comms[k];
+        }
+        const ncclResult_t r = f(c);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--in_call[k] == 0 && abort_pending[k]) {
+                abort_pending[k] = 0;
+                if (comms[k]) { if (rccl().CommAbort) (void)rccl().CommAbort(comms[k]); comms[k] = nullptr; }
+            }
+        }
+        return r;
+    }
     // bounded wait for everything queued on a rank's stream (collectives included); false also when a PEER brought the communicators down
     bool wait_stream(Shard& sh, hipStream_t st, const char* what) {
         const bool done = wait_stream_raw(sh, st, what);
@@ -144,12 +172,12 @@ struct sts_multi {
         Rccl& R = rccl();
         const int nd = (int)engines.size();
         const long long mine = sh.rc == STS_OK && !sh.utt.empty() ? (long long)eng.total_samples : 0;    // a failed shard still takes part
-        auto ck = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess) { if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + R.GetErrorString(r); } abort_all(); } return r == ncclSuccess; };
+        auto ck = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess) { if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + (broken() ? "the communicators were aborted by a peer's failure" : R.GetErrorString(r)); } abort_all(); } return r == ncclSuccess; };
         auto hk = [&](hipError_t e, const char* what) { if (e != hipSuccess && sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + hipGetErrorString(e); } return e == hipSuccess; };
         long long host_words[65];
         // ---- round 1: sample counts
         bool ok = hk(hipMemcpyAsync(d_counts[k], &mine, sizeof(long long), hipMemcpyHostToDevice, eng.stream), "count upload");
-        ok = ok && ck(R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, comms[k], eng.stream), "ncclAllGather (counts)");
+        ok = ok && ck(rccl_call(k, [&](ncclComm_t cm) { return R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, cm, eng.stream); }), "ncclAllGather (counts)");
         ok = ok && hk(hipMemcpyAsync(host_words, d_counts[k] + 1, sizeof(long long) * nd, hipMemcpyDeviceToHost, eng.stream), "count download");
         ok = ok && wait_stream(sh, eng.stream, "count exchange");
         if (!ok) { abort_all(); return; }                    // (a local HIP failure: nobody waits for this rank once the communicators are down)
@@ -173,7 +201,7 @@ struct sts_multi {
             ready = d_gather && h_gather && gather_cap >= need && h_gather_cap >= need ? 1 : 0;
         }
         ok = hk(hipMemcpyAsync(d_counts[k], &ready, sizeof(long long), hipMemcpyHostToDevice, eng.stream), "ready upload");
-        ok = ok && ck(R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, comms[k], eng.stream), "ncclAllGather (ready)");
+        ok = ok && ck(rccl_call(k, [&](ncclComm_t cm) { return R.AllGather(d_counts[k], d_counts[k] + 1, sizeof(long long), ncclInt8, cm, eng.stream); }), "ncclAllGather (ready)");
         ok = ok && hk(hipMemcpyAsync(host_words, d_counts[k] + 1, sizeof(long long) * nd, hipMemcpyDeviceToHost, eng.stream), "ready download");
         ok = ok && wait_stream(sh, eng.stream, "ready exchange");
         if (!ok) { abort_all(); return; }
@@ -182,18 +210,27 @@ struct sts_multi {
                 if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = "RCCL gather cancelled: rank " + std::to_string(p) + " could not allocate its buffers"; }
                 return;
             }
-        // ---- the transfer
+        // ---- the transfer (out of HBM: an engine of an RCCL handle never runs with host_pcm, so a host-resident PCM cannot occur here)
+        if (mine > 0 && !eng.pcm_hbm()) { if (sh.rc == STS_OK) { sh.rc = STS_ESTATE; sh.err = "RCCL gather: the shard's PCM is not in device memory"; } abort_all(); return; }
         if (k > 0) {
-            if (mine > 0 && ck(R.Send(eng.d_pcm, (size_t)mine, ncclHalf, 0, comms[k], eng.stream), "ncclSend"))
+            if (mine > 0 && ck(rccl_call(k, [&](ncclComm_t cm) { return R.Send(eng.pcm_hbm(), (size_t)mine, ncclHalf, 0, cm, eng.stream); }), "ncclSend"))
                 (void)wait_stream(sh, eng.stream, "ncclSend");      // the engine's PCM buffer is free again
             return;
         }
-        bool posted = ck(R.GroupStart(), "ncclGroupStart");
-        for (int p = 1; p < nd && posted; p++)
-            if (counts[p] > 0) posted = ck(R.Recv(d_gather + offsets[p], (size_t)counts[p], ncclHalf, p, comms[0], eng.stream), "ncclRecv");
-        posted = ck(R.GroupEnd(), "ncclGroupEnd") && posted;
+        // (the receives of all peers form ONE group = one host call on rank 0's communicator)
+        const char* what = "ncclGroupStart";
+        const bool posted = ck(rccl_call(0, [&](ncclComm_t cm) {
+            ncclResult_t r = R.GroupStart();
+            if (r != ncclSuccess) return r;
+            ncclResult_t first = ncclSuccess;
+            for (int p = 1; p < nd && first == ncclSuccess; p++)
+                if (counts[p] > 0) { first = R.Recv(d_gather + offsets[p], (size_t)counts[p], ncclHalf, p, cm, eng.stream); if (first != ncclSuccess) what = "ncclRecv"; }
+            r = R.GroupEnd();
+            if (first == ncclSuccess && r != ncclSuccess) what = "ncclGroupEnd";
+            return first != ncclSuccess ? first : r;
+        }), what);
         if (!posted) return;
-        if (mine > 0) hk(hipMemcpyAsync(d_gather + offsets[0], eng.d_pcm, (size_t)mine * 2, hipMemcpyDeviceToDevice, eng.stream), "own shard");
+        if (mine > 0) hk(hipMemcpyAsync(d_gather + offsets[0], eng.pcm_hbm(), (size_t)mine * 2, hipMemcpyDeviceToDevice, eng.stream), "own shard");
         if (gather_total > 0) hk(hipMemcpyAsync(h_gather, d_gather, (size_t)gather_total * 2, hipMemcpyDeviceToHost, eng.stream), "gather download");
         (void)wait_stream(sh, eng.stream, "gather");
     }
@@ -221,13 +258,20 @@ struct sts_multi {
                     sh.n_samples = eng.n_samples;
                     sh.pcm.resize((size_t)std::max<int64_t>(1, eng.total_samples));
                     if (eng.h_pcm) memcpy(sh.pcm.data(), eng.h_pcm, (size_t)eng.total_samples * 2);   // downloaded inside the run
-                    else if (hipMemcpyAsync(sh.pcm.data(), eng.d_pcm, (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
+                    else if (!eng.pcm_hbm() || hipMemcpyAsync(sh.pcm.data(), eng.pcm_hbm(), (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
                              hipStreamSynchronize(eng.stream) != hipSuccess) { sh.rc = STS_EDEVICE; sh.err = "PCM download failed"; }
                 } else {
                     sh.err = eng.error();
                 }
             }
             if (gather_mode == 1) {       // every rank takes part, also with an empty or failed shard
+                {   // all shards have run before the first collective is posted: the bounded waits inside rccl_gather then cover the
+                    // collective alone, not the slowest peer's synthesis (an imbalanced batch must not trip the timeout: ADVICE r04)
+                    std::unique_lock<std::mutex> lk(mu);
+                    const int64_t ge = gather_epoch;
+                    if (++gather_arrived == (int)engines.size()) { gather_arrived = 0; gather_epoch++; cv_done.notify_all(); }
+                    else cv_done.wait(lk, [&] { return gather_epoch != ge || stop; });
+                }
                 bool alive; { std::lock_guard<std::mutex> lk(mu); alive = !rccl_broken; }
                 if (alive) rccl_gather(k);
                 else if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = "RCCL communicators were aborted by an earlier failure"; }
@@ -282,7 +326,11 @@ int sts_multi_gather_mode(const sts_multi* m) { return m ? m->gather_mode : 0; }
 // Test hook: the shared library that provides the nccl* entry points (default: librccl.so.1) and whether STS_MULTI_RCCL may list a
 // device more than once (real RCCL refuses that; tests/fake_rccl emulates N ranks on ONE GPU).  Takes effect for handles created
 // afterwards, and only before the first successful load in the process.
+// Gated: refused unless the process environment carries STS_TEST_HOOKS=1 -- a caller of the drop-in library cannot swap the
+// collective library or lift the distinct-device check by accident.
 int sts_multi_set_rccl_library(const char* path, int allow_repeated_devices) {
+    const char* gate = getenv("STS_TEST_HOOKS");
+    if (!gate || strcmp(gate, "1") != 0) return multi_err(STS_ESTATE, "test hook: set STS_TEST_HOOKS=1 in the environment to enable it");
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     Rccl& R = rccl();
     if (R.h) return multi_err(STS_ESTATE, "an RCCL library is already loaded in this process");
@@ -330,6 +378,7 @@ int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* de
                 for (auto& e : m->engines) e->host_pcm = true;
             } else {
                 m->gather_mode = 1;
+                m->in_call.assign(n_devices, 0); m->abort_pending.assign(n_devices, 0);
                 m->d_counts.assign(n_devices, nullptr);
                 for (int k = 0; k < n_devices; k++) {
                     (void)hipSetDevice(devices[k]);

@@ -66,7 +66,7 @@ struct sts_pool {
                 if (rc == STS_OK) {
                     all.resize((size_t)(eng.total_samples > 0 ? eng.total_samples : 1));
                     if (eng.h_pcm) memcpy(all.data(), eng.h_pcm, (size_t)eng.total_samples * 2);   // downloaded inside the run
-                    else if (hipMemcpyAsync(all.data(), eng.d_pcm, (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
+                    else if (!eng.pcm_hbm() || hipMemcpyAsync(all.data(), eng.pcm_hbm(), (size_t)eng.total_samples * 2, hipMemcpyDeviceToHost, eng.stream) != hipSuccess ||
                              hipStreamSynchronize(eng.stream) != hipSuccess)
                         rc = STS_EDEVICE;
                 }

@@ -196,12 +196,13 @@ class Synthesizer:
 
     def run_batch(self, ids, sid: Optional[Sequence[int]] = None, length_scale: Optional[Sequence[float]] = None) -> np.ndarray:
         """Runs the batch (ids: a sequence of id sequences, or a PreparedBatch) and leaves the PCM on the device (and, with
-        set_host_pcm, in the engine's pinned host buffer); returns per-utterance sample counts."""
+        set_host_pcm, in the engine's pinned host buffer); returns per-utterance sample counts (a fresh array per call).  Views handed out by
+        pcm_host(copy=False) alias the engine's pinned buffer: the next run on this engine rewrites them in place."""
         p = ids if isinstance(ids, PreparedBatch) else PreparedBatch(ids, sid, length_scale)
         _check(self.lib, self.lib.sts_run_batch(self.h, p.B, p.ptrs, p.n_p, p.sid_p, p.ls_p, p.n_out_p, p.total_ref))
         self._total = int(p.total.value)
-        self._n_out = p.n_out
-        return p.n_out
+        self._n_out = p.n_out.copy()       # (the prepared object's own array is overwritten by its next run: ADVICE r04)
+        return self._n_out
 
     def pcm_host(self, copy: bool = True) -> np.ndarray:
         """PCM of the last run on the host.  copy=False: a read-only view of the engine's pinned download buffer (valid until the
@@ -255,8 +256,8 @@ class Synthesizer:
         _check(self.lib, self.lib.sts_set_conv_mode(self.h, mode))
 
     def debug_set(self, key: str, value: int):
-        """Test hooks (include/summertts_hip.h sts_debug_set): 'attn_block_min_wgs' | 'front_mode'."""
-        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "front_mode": 2, "pk_trace": 3, "trunk_mode": 4, "flow_fused": 5, "launch_ahead": 6, "attn_reg": 7, "dds_tail": 8, "pcm_direct": 9}[key], int(value)))
+        """Test hooks (include/summertts_hip.h sts_debug_set): 'attn_block_min_wgs' | 'flow_fused' | 'launch_ahead' | ..."""
+        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "flow_fused": 5, "launch_ahead": 6, "attn_reg": 7, "dds_tail": 8, "pcm_direct": 9}[key], int(value)))
 
     def set_profiling(self, on: bool):
         _check(self.lib, self.lib.sts_set_profiling(self.h, 1 if on else 0))

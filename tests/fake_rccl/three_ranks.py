@@ -31,6 +31,13 @@ cfg = sb.tiny_cfg("ms_hifigan_sdp")
 blob = sb.make_blob(cfg, 21)
 port = pyref.PortModel(blob)
 syn = engine.Synthesizer(blob)
+try:                                   # the hook is gated: without STS_TEST_HOOKS=1 in the environment the library refuses it
+    os.environ.pop("STS_TEST_HOOKS", None)
+    engine.MultiDevice.set_rccl_library(FAKE, allow_repeated_devices=True)
+    check("the test hook is refused without STS_TEST_HOOKS=1", False)
+except engine.StsError:
+    check("the test hook is refused without STS_TEST_HOOKS=1", True)
+os.environ["STS_TEST_HOOKS"] = "1"
 engine.MultiDevice.set_rccl_library(FAKE, allow_repeated_devices=True)
 md = engine.MultiDevice(blob, [0, 0, 0], gather="rccl")
 check("gather mode is rccl with three emulated ranks", md.gather_mode() == "rccl" and md.device_count() == 3)
