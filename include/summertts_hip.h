@@ -158,11 +158,14 @@ typedef struct sts_profile {
     int64_t conv_math_fallbacks;          /* sts_set_conv_math(3): calls of this engine so far that were repeated in the split-bf16 form */
     int32_t conv_math_pinned;             /* 1: after two such calls in a row the engine now stays in the split-bf16 form (until sts_set_conv_math) */
     int32_t launch_ahead;                 /* 1: this run enqueued flow + decoder before the frame count reached the host (one utterance; ms_sync_wait_host ~ 0) */
-    int64_t launch_ahead_misses;          /* launch-ahead runs of this engine so far whose predicted frame capacity was too small (flow + decoder repeated) */
+    int64_t launch_ahead_misses;          /* launch-ahead runs of this engine so far whose frame count fell outside the predicted 64-frame bucket (flow + decoder repeated) */
     float us_host_setup;                  /* host time from the entry of the run to the first launch being enqueued (input checks, tables, the one upload) */
     float us_host_enqueue;                /* host time from the entry of the run to the last launch being enqueued (the GPU runs behind it) */
     float us_host_tail;                   /* host time from the return of the run's last stream synchronisation to the return of the call */
 } sts_profile;
+/* enable: 0 off; 1 HIP events at all eight stage boundaries of a run (ms_text_encoder ... ms_decoder_mfma); 2 only the two events around the
+ * decoder's matrix-core region (ms_decoder_mfma; the per-stage times read 0) -- every event is a barrier packet between two kernels
+ * (5-10 us of idle GPU each), so a caller who wants the dominant kernel family timed inside a step it also times uses 2. */
 int sts_set_profiling(sts_engine* e, int enable);
 /* The struct only ever grows at its end (STS_ABI_VERSION counts the revisions).  sts_get_profile_ex copies min(size_bytes,
  * sizeof(sts_profile)) bytes, so a client compiled against an older header passes ITS sizeof and is never overrun;

@@ -168,7 +168,7 @@ int sts_debug_set(sts_engine* e, int key, int value) {
     }
 }
 int sts_set_host_pcm(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.host_pcm = enable != 0; return STS_OK; }
-int sts_set_profiling(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.profiling = enable != 0; return STS_OK; }
+int sts_set_profiling(sts_engine* e, int enable) { if (!e) return set_err(STS_EINVAL, "null engine"); e->eng.profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0); return STS_OK; }
 
 int sts_abi_version(void) { return STS_ABI_VERSION; }
 int sts_build_flags(void) {

@@ -106,7 +106,9 @@ bool Engine::ensure_pinned(size_t bytes) {
 
 void Engine::stage_begin(int s) { cur_stage_ = s; }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-void Engine::mark(int i) { if (profiling) (void)hipEventRecord(ev_[i], stream); }
+// profiling 1: all eight stage events; 2: only the two that bracket the decoder's matrix-core region (events 5 / 6) -- every event is a barrier
+// packet between two kernels (5-10 us of bubble each), so the headline step pays for two of them, not eight
+void Engine::mark(int i) { if (profiling == 1 || (profiling == 2 && (i == 5 || i == 6))) (void)hipEventRecord(ev_[i], stream); }
 
 // builds the kernel arguments of one conv and books its FLOPs / minimum HBM bytes
 // default arithmetic of the trunk convs: STS_CONV_MATH = f16x2 (two fp16 terms, three products: the default) | bf16x3 (three bf16
@@ -1369,7 +1371,10 @@ int Engine::run_output(RunCtx& c) {
     prof.conv_math_fallbacks = h2_fallbacks; prof.conv_math_pinned = h2_disabled ? 1 : 0;
     prof.bytes_text_encoder = bytes_[0]; prof.bytes_duration = bytes_[1]; prof.bytes_flow = bytes_[2];
     prof.ms_sync_wait_host = (float)sync_wait_ms_; prof.launch_ahead = ahead ? 1 : 0; prof.launch_ahead_misses = ahead_misses;
-    if (profiling) {
+    if (profiling == 2) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, ev_[5], ev_[6]); prof.ms_decoder_mfma = t;
+    } else if (profiling) {
         float t = 0;
         (void)hipEventElapsedTime(&t, ev_[0], ev_[1]); prof.ms_text_encoder = t;
         (void)hipEventElapsedTime(&t, ev_[1], ev_[2]); prof.ms_duration = t;

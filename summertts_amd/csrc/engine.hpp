@@ -77,7 +77,7 @@ public:
     sts_profile prof{};
     // controls
     std::vector<int32_t> forced_dur; bool have_forced = false;
-    bool record_taps = false, profiling = false;
+    bool record_taps = false; int profiling = 0;       // profiling: 0 off, 1 all stage events, 2 the matrix-core region's two events only (sts_set_profiling)
     int conv_mode = 0;
     int conv_math = 3;                 // 0 = split-bf16 trunk convs (conv_bf3.hip), 1 = exact-fp32 MFMA, 3 = two-term fp16 (sts_set_conv_math)
     long h2_fallbacks = 0;             // runs repeated in split-bf16 because an activation left fp16's range (conv_math 3)

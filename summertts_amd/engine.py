@@ -259,8 +259,10 @@ class Synthesizer:
         """Test hooks (include/summertts_hip.h sts_debug_set): 'attn_block_min_wgs' | 'flow_fused' | 'launch_ahead' | ..."""
         _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "flow_fused": 5, "launch_ahead": 6, "attn_reg": 7, "dds_tail": 8, "pcm_direct": 9}[key], int(value)))
 
-    def set_profiling(self, on: bool):
-        _check(self.lib, self.lib.sts_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, on):
+        """False / True: no / all eight stage events per run; 2: only the two events around the decoder's matrix-core region (the
+        per-stage times of Profile then read 0; every event is a barrier packet between two kernels, so the timed headline step uses 2)."""
+        _check(self.lib, self.lib.sts_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))
 
     def profile(self) -> dict:
         p = Profile()

@@ -92,6 +92,11 @@ class ModelCfg:
     head_gain: float = 0.25
     mag_bias: float = -1.0
     istft_mag_bias: float = 0.0
+    # weight statistics: "gaussian" = i.i.d. N(0, gain / sqrt(fan_in)) (rounds 1-4); "realistic" (round 5) = what a
+    # weight-normed, trained checkpoint looks like to the kernels' range logic: a log-normal gain per output channel (sigma 1), one
+    # weight in a thousand 20x larger, every conv with a bias of O(0.1), LayerNorm gamma ~ U(0.5, 2) and beta ~ N(0, 0.3) -- each
+    # tensor rescaled to the rms the Gaussian recipe gives it, so that activations stay O(1) through the ~100 layers
+    stats: str = "gaussian"
 
     @property
     def hop_total(self) -> int:
@@ -151,10 +156,27 @@ def tiny_cfg(kind: str) -> ModelCfg:
 class _W:
     """Append-only float32 stream."""
 
-    def __init__(self, seed: int):
+    def __init__(self, seed: int, stats: str = "gaussian"):
+        if stats not in ("gaussian", "realistic"):
+            raise ValueError(stats)
         self.rng = np.random.default_rng(seed)
+        self.realistic = stats == "realistic"
         self.parts: List[np.ndarray] = []
         self.n = 0
+
+    def shape_weights(self, wt: np.ndarray) -> np.ndarray:
+        """realistic: per-output-channel log-normal gain, sparse outliers, the tensor's rms kept (wt is [out][k][in])."""
+        if not self.realistic or wt.size < 2:
+            return wt
+        rms0 = float(np.sqrt((wt.astype(np.float64) ** 2).mean()))
+        g = np.exp(self.rng.standard_normal((wt.shape[0],) + (1,) * (wt.ndim - 1)))
+        out = wt.astype(np.float64) * g
+        out[self.rng.random(wt.shape) < 1e-3] *= 20.0
+        rms1 = float(np.sqrt((out ** 2).mean()))
+        return (out * (rms0 / rms1 if rms1 > 0 else 1.0)).astype(np.float32)
+
+    def bias(self, n: int, std: float) -> np.ndarray:
+        return self.normal((n,), max(std, 0.1) if self.realistic else std)
 
     def ints(self, *vals):
         a = np.asarray(vals, dtype=np.float32).ravel()
@@ -175,24 +197,29 @@ class _W:
 
 def _conv1d(w: _W, out_ch, in_ch, k, pad=0, dil=1, bias=True, gain=0.7, bias_std=0.02):
     """nn_conv1d.cpp:32-46.  W memory order [out][k][in]; depthwise convs carry in_ch=1."""
+    bias = bias or w.realistic          # ("biases everywhere": also the tails upstream VITS builds without one)
     w.ints(out_ch, in_ch, k, pad, dil, 1 if bias else 0)
-    w.arr(w.normal((out_ch, k, in_ch), gain / np.sqrt(in_ch * k)))
+    w.arr(w.shape_weights(w.normal((out_ch, k, in_ch), gain / np.sqrt(in_ch * k))))
     if bias:
-        w.arr(w.normal((out_ch,), bias_std))
+        w.arr(w.bias(out_ch, bias_std))
 
 
 def _convT1d(w: _W, out_ch, in_ch, k, stride, pad, bias=True, gain=0.7):
     """nn_conv1d_transposed.cpp:33-48.  W memory order [out][k][in]."""
     w.ints(out_ch, in_ch, k, pad, 1, 1 if bias else 0, stride)
     # each output sample receives ~k/stride taps * in_ch products
-    w.arr(w.normal((out_ch, k, in_ch), gain / np.sqrt(in_ch * max(1.0, k / stride))))
+    w.arr(w.shape_weights(w.normal((out_ch, k, in_ch), gain / np.sqrt(in_ch * max(1.0, k / stride)))))
     if bias:
-        w.arr(w.normal((out_ch,), 0.02))
+        w.arr(w.bias(out_ch, 0.02))
 
 
 def _ln(w: _W, size):
     """nn_layer_norm.cpp:17-31."""
     w.ints(size)
+    if w.realistic:
+        w.arr(w.rng.uniform(0.5, 2.0, size).astype(np.float32))
+        w.arr(w.normal((size,), 0.3))
+        return
     w.arr(1.0 + w.normal((size,), 0.05))
     w.arr(w.normal((size,), 0.05))
 
@@ -275,7 +302,7 @@ def _decoder(w: _W, cfg: ModelCfg):
     if cfg.dec_type == DEC_ISTFT:
         # same stream as _conv1d(w, 2 * nbin, ch, 7, pad=3, gain=head_gain, bias_std=0.01), plus the log-magnitude shift
         w.ints(2 * nbin, ch, 7, 3, 1, 1)
-        w.arr(w.normal((2 * nbin, 7, ch), cfg.head_gain / np.sqrt(ch * 7)))
+        w.arr(w.shape_weights(w.normal((2 * nbin, 7, ch), cfg.head_gain / np.sqrt(ch * 7))))
         bs = w.normal((2 * nbin,), 0.01)
         bs[:nbin] += np.float32(cfg.istft_mag_bias)
         w.arr(bs)
@@ -283,7 +310,7 @@ def _decoder(w: _W, cfg: ModelCfg):
     # log-magnitude / phase heads; small so exp() stays O(1) and the waveform inside (-1,1)
     out = cfg.subbands * 2 * nbin
     w.ints(out, ch, 7, 3, 1, 1)
-    wt = w.normal((out, 7, ch), cfg.head_gain / np.sqrt(ch * 7))
+    wt = w.shape_weights(w.normal((out, 7, ch), cfg.head_gain / np.sqrt(ch * 7)))
     bs = w.normal((out,), 0.01)
     for b in range(cfg.subbands):       # push log-magnitudes down: |X_k| ~ e^-1
         bs[b * 2 * nbin: b * 2 * nbin + nbin] += np.float32(cfg.mag_bias)
@@ -365,7 +392,7 @@ def _dur(w: _W, cfg: ModelCfg):
         _ln(w, f)
         # proj: small weights, bias = dur_bias
         w.ints(1, f, 1, 0, 1, 1)
-        w.arr(w.normal((1, 1, f), 0.35 / np.sqrt(f)))
+        w.arr(w.shape_weights(w.normal((1, 1, f), 0.35 / np.sqrt(f))))
         w.arr(np.asarray([cfg.dur_bias], np.float32))
         if cfg.is_ms:
             _conv1d(w, cfg.hidden, cfg.gin, 1, gain=0.3)
@@ -373,7 +400,7 @@ def _dur(w: _W, cfg: ModelCfg):
 
 def make_blob(cfg: ModelCfg, seed: int = 1234) -> np.ndarray:
     """Return the float32 model blob (acoustic sections only; no text-frontend sections)."""
-    w = _W(seed)
+    w = _W(seed, cfg.stats)
     w.ints(cfg.is_ms, cfg.lang, cfg.dur_type, cfg.dec_type)
     _text_encoder(w, cfg)
     _decoder(w, cfg)

@@ -38,7 +38,7 @@ def port_built():
 def golden_files():
     """Tiny-model fixtures of round 1 (one utterance each, full taps)."""
     return sorted(p for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz"))
-                  if not os.path.basename(p).startswith(("full_", "amp_", "loud_")))
+                  if not os.path.basename(p).startswith(("full_", "amp_", "loud_", "real_")))
 
 
 def golden_files_v2(prefix):

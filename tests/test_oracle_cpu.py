@@ -54,6 +54,40 @@ def test_port_matches_live_reference(kind, port_built):
         assert np.abs(p[k] - r[k]).max() <= TAP_MAXABS_TOL, k
 
 
+@pytest.mark.parametrize("path", [p for p in golden_files_v2("real_tiny_")], ids=lambda p: p.split("/")[-1])
+def test_port_matches_reference_golden_on_realistic_weight_statistics(path, port_built):
+    """Round 5: the restatement against outputs the compiled reference produced on blobs with the statistics of a trained,
+    weight-normed checkpoint (synth_blob.py stats="realistic": log-normal per-channel gains, sparse 20x outliers, biases on every
+    conv, LayerNorm gamma ~ U(0.5, 2) / beta ~ N(0, 0.3)) -- the oracle must not be pinned on i.i.d. Gaussian weights alone."""
+    g, cfg, blob, utts, stride = load_golden_v2(path)
+    assert cfg.stats == "realistic"
+    port = pyref.PortModel(blob)
+    assert port.consumed == blob.size
+    for u, ids, sid, ls, dur, pcm, wave in utts:
+        o = port.infer_ids(ids, sid, ls, taps=True)
+        assert (o["durations"] == dur).all()
+        assert_wave_close(o["wave"][::stride], wave, path)
+        assert_pcm_close(o["pcm"], pcm, path)
+        z = g[f"z_{u}"]
+        assert np.abs(o["z"][:, ::int(g["z_stride"])] - z).max() <= TAP_MAXABS_TOL * max(1.0, float(np.abs(z).max()))
+
+
+@pytest.mark.skipif(not pyref.have_ref(), reason="oracle/_ref (real reference) not built on this machine")
+@pytest.mark.parametrize("kind", TINY)
+def test_port_matches_live_reference_on_realistic_weight_statistics(kind, port_built):
+    import dataclasses
+    cfg = dataclasses.replace(sb.tiny_cfg(kind), stats="realistic")
+    blob = sb.make_blob(cfg, 41)
+    ids = sb.synthetic_ids(15, cfg.vocab, salt=2)
+    r = pyref.RefModel(blob).infer_ids(ids, 1, 0.95, taps=True)
+    p = pyref.PortModel(blob).infer_ids(ids, 1, 0.95, taps=True)
+    assert (r["durations"] == p["durations"]).all()
+    assert_wave_close(p["wave"], r["wave"], kind)
+    assert_pcm_close(p["pcm"], r["pcm"], kind)
+    for k in ("x_enc", "m", "logw", "z_p", "z"):
+        assert np.abs(p[k] - r[k]).max() <= TAP_MAXABS_TOL * max(1.0, float(np.abs(r[k]).max())), k
+
+
 def test_port_forced_durations_and_short_inputs(port_built):
     cfg = sb.tiny_cfg("hifigan_fix")
     blob = sb.make_blob(cfg, 3)
@@ -94,13 +128,17 @@ def test_full_size_golden_fixtures_are_well_formed():
     """The full-size fixtures are too slow for the restatement on a CPU-only box; check what can be checked without
     running a model: recipe hash, batch definition, PCM == trunc(wave * 32737) on the stored (strided) samples."""
     paths = golden_files_v2("full_")
-    assert len(paths) >= 9      # round 3 added the bench's own T = 128 workload and the 32- / 64-utterance batches
-    for path in paths:
+    assert len(paths) >= 10     # round 3 added the bench's own T = 128 workload and the 32- / 64-utterance batches, round 5 the full-size iSTFT decoder
+    real = [p for p in golden_files_v2("real_") if "real_tiny_" not in p]
+    assert len(real) >= 4       # round 5: realistic weight statistics, incl. the iSTFT decoder
+    for path in paths + real:
         g = np.load(path)
         assert str(g["size"]) == "full" and int(g["wave_stride"]) == 8
         for u in g["utts"]:
             pcm, wave, dur = g[f"pcm_{u}"], g[f"wave_{u}"], g[f"dur_{u}"]
             assert pcm.size % int(dur.sum()) == 0 and pcm.size // int(dur.sum()) == 256
+            if f"z_{u}" in g:
+                assert g[f"z_{u}"].shape[1] == (int(dur.sum()) + int(g["z_stride"]) - 1) // int(g["z_stride"])
             expect = np.trunc(wave.astype(np.float32) * np.float32(32737)).astype(np.int64)
             assert (pcm[::8].astype(np.int64) == expect).all()
             assert g[f"ids_{u}"].size >= 64
