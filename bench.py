@@ -244,6 +244,156 @@ def kernel_build_id() -> str:
     return h.hexdigest()[:16]
 
 
+def measure_config(eng, torch, n_cfg: int, conv_math: str, steps: int = 5, warmup: int = 2, cpu_threads: int = 16, with_cpu: bool = True):
+    """One BASELINE.json config (per-GPU share) measured in this process next to the headline: K timed steps with the two matrix-core-region
+    events (value, ms/step, trunk roofline), three more with all stage events (stage split), and -- with_cpu -- the shortest utterance of
+    the batch run ONCE through the compiled reference (oracle/_ref) on the host cores: parity of that utterance + a one-repetition CPU figure."""
+    from summertts_amd import synth_blob as sb
+    pz = CONFIG_PRESETS[n_cfg]
+    cfg = sb.full_cfg(pz["workload"])
+    blob = sb.make_blob(cfg, 1234)
+    lens = np.random.default_rng(1234).integers(64, 257, size=pz["batch"]).tolist() if pz["ragged"] else [pz["phonemes"]] * pz["batch"]
+    ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=u) for u, t in enumerate(lens)]
+    syn = eng.Synthesizer(blob, device=0)
+    res = {"workload": pz["label"]}
+    try:
+        syn.set_conv_math(conv_math)
+        sid = [u % max(1, syn.get_speaker_num()) for u in range(len(ids))]
+        ls = [1.0] * len(ids)
+        prepared = syn.prepare(ids, sid, ls)
+        for _ in range(warmup):
+            syn.run_batch(prepared)
+        syn.set_profiling(2)
+        torch.cuda.synchronize()
+        acc, samples = {}, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            samples += int(syn.run_batch(prepared).sum())
+            for k, v in syn.profile().items():
+                acc[k] = acc.get(k, 0.0) + float(v)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        products = 3 if conv_math == "f16x2" else (BF16_PRODUCTS_PER_F32 if conv_math == "bf16x3" else 0)
+        peak = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS
+        mm = acc.get("ms_decoder_mfma", 0.0)
+        ach = (acc.get("flops_decoder_mfma", 0.0) / (mm * 1e-3)) / 1e12 if mm > 0 else 0.0
+        res.update(value=samples / el, unit="samples/s", x_realtime_16khz=samples / el / 16000.0, steps=steps, warmup=warmup, ms_per_step=1e3 * el / steps,
+                   utterances=len(ids), samples_per_step=samples // steps, conv_math=conv_math,
+                   host_sync_wait_ms_per_step=acc.get("ms_sync_wait_host", 0.0) / steps,
+                   roofline={"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                             "launches_per_step": acc.get("decoder_mfma_launches", 0.0) / steps,
+                             "avg_launch_us": 1e3 * mm / max(1.0, acc.get("decoder_mfma_launches", 0.0))})
+        syn.set_profiling(True)
+        sacc = {}
+        for _ in range(3):
+            syn.run_batch(prepared)
+            for k, v in syn.profile().items():
+                sacc[k] = sacc.get(k, 0.0) + float(v)
+        res["stage_ms_per_step"] = {k[3:]: sacc.get(k, 0.0) / 3 for k in ("ms_text_encoder", "ms_duration", "ms_flow", "ms_decoder")}
+        if with_cpu:
+            from oracle import pyref
+            cand = [u for u in range(len(ids)) if sid[u] == 0] or list(range(len(ids)))
+            u0 = min(cand, key=lambda u: len(ids[u]))
+            syn.set_record_taps(True)
+            n_out = [int(v) for v in syn.run_batch(ids, sid, ls)]
+            s0, p0 = sum(n_out[:u0]), sum(len(a) for a in ids[:u0])
+            got = {"pcm": syn.pcm_host()[s0:s0 + n_out[u0]].copy(), "durations": syn.durations(sum(len(a) for a in ids))[p0:p0 + len(ids[u0])].copy(),
+                   "wave": syn.tap("wave")[0][s0:s0 + n_out[u0]].copy()}
+            syn.set_record_taps(False)
+            if pyref.have_ref():
+                _set_omp_threads(cpu_threads)
+                ref = pyref.RefModel(blob)
+                ref.infer_ids(sb.synthetic_ids(6, cfg.vocab), 0, 1.0)                 # page-in / OpenMP start-up
+                tc = time.perf_counter()
+                ro = ref.infer_ids(ids[u0], sid[u0], ls[u0])
+                tc = time.perf_counter() - tc
+                ref.close()
+                res["parity"] = dict(parity_report(ro, got), checked=f"utterance {u0} of the batch ({len(ids[u0])} phonemes, speaker {sid[u0]}) vs the compiled reference, "
+                                                                     "same blob and ids; tolerance: durations equal, PCM <= 1 LSB, wave RMSE <= 2e-6")
+                res["cpu_baseline"] = {"value": ro["wave"].size / tc, "unit": "samples/s", "x_realtime": ro["wave"].size / tc / 16000.0, "cores": cpu_threads,
+                                       "kind": "reference", "sample": f"1 x utterance {u0} ({len(ids[u0])} phonemes -> {ro['wave'].size} samples), {tc:.2f} s, "
+                                                                      f"{cpu_threads} OpenMP threads, one repetition (a bounded sample)"}
+            else:
+                res["parity"] = None
+    except Exception as e:      # an extra config must never take the headline down with it
+        res["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        syn.close()
+    return res
+
+
+def native_multi_bench(args) -> int:
+    """`--gpus N --multi native`: ONE process, sts_multi_create_ex(devices 0..N-1, STS_MULTI_RCCL) -- the library's own utterance sharding and
+    RCCL gather (ncclAllGather of the counts, ncclSend / grouped ncclRecv of the int16 PCM to device 0, one download): the code a C++ caller
+    of the drop-in library gets, which the torch.distributed path of the default `--gpus N` does not exercise.  Same JSON
+    line: value = samples of ALL devices / wall time of K calls (weak scaling: args.batch utterances per device), plus the communicator size as
+    RCCL reports it and rank 0's gather time.  STS_BENCH_RCCL_LIB=<path> + --share-gpu (tests): N emulated ranks on device 0 against
+    tests/fake_rccl (needs STS_TEST_HOOKS=1)."""
+    eng = importlib.import_module(os.environ.get("STS_BENCH_ENGINE", "summertts_amd.engine"))
+    stub = getattr(eng, "IS_STUB", False)
+    from summertts_amd import synth_blob as sb
+    from summertts_amd import sharding
+    N = max(1, args.gpus)
+    cfg = sb.full_cfg(args.workload) if not stub else sb.tiny_cfg("hifigan_fix")
+    if os.environ.get("STS_BENCH_TINY") == "1":
+        cfg = sb.tiny_cfg("ms_hifigan_sdp" if args.workload.startswith("ms_hifigan") else "hifigan_sdp")
+    blob = sb.make_blob(cfg, 1234)
+    fake = os.environ.get("STS_BENCH_RCCL_LIB")
+    if fake:
+        eng.MultiDevice.set_rccl_library(fake, allow_repeated_devices=True)
+    devices = [0] * N if args.share_gpu else list(range(N))
+    md = eng.MultiDevice(blob, devices, gather="rccl")
+    if hasattr(md, "set_conv_math"):
+        md.set_conv_math(args.conv_math)
+    gB = N * args.batch
+    lens = np.random.default_rng(1234).integers(64, 257, size=gB).tolist() if args.ragged else [args.phonemes] * gB
+    ids = [sb.synthetic_ids(int(t), cfg.vocab, salt=u) for u, t in enumerate(lens)]
+    spk = 1
+    try:
+        spk = max(1, int(md.lib.sts_multi_speaker_num(md.h)))
+    except Exception:
+        pass
+    sid = [u % spk for u in range(gB)]
+    ls = [1.0] * gB
+    slot = [int(v) for v in md.shard_of([len(a) for a in ids])]
+    for _ in range(args.warmup):
+        md.infer_batch(ids, sid, ls)
+    lat, samples, gms = [], 0, 0.0
+    per_dev = [0] * N
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        pcm = md.infer_batch(ids, sid, ls)
+        lat.append(time.perf_counter() - ts)
+        gms += md.last_gather_ms()
+        for u, a_ in enumerate(pcm):
+            samples += int(a_.size)
+            per_dev[slot[u]] += int(a_.size)
+    elapsed = time.perf_counter() - t0
+    steps = max(1, args.steps)
+    out = {
+        "metric": "audio samples/sec (acoustic model + vocoder, phoneme ids -> int16 PCM on host), single_speaker_fast-shaped synthetic blob",
+        "value": samples / elapsed, "unit": "samples/s", "x_realtime_16khz": samples / elapsed / 16000.0, "n_gpus": N, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_latency_ms": 1e3 * float(np.median(lat)), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": f"f32 (trunk arithmetic {args.conv_math}: see the one-GPU line)",
+        "data": "synthetic (seeded random weights in the reference .bin grammar)",
+        "config": {"workload": config_label(args) + f" [synthetic '{args.workload}' blob; batch={args.batch}/GPU]", "global_batch": gB,
+                   "parallelism": f"utterance-sharded x{N}, one process (sts_multi)", "launched_by": "bench.py --multi native (one process)",
+                   "kernel_build_id": kernel_build_id(), "conv_math": args.conv_math},
+        "multi_gpu": {"mode": "native: sts_multi_create_ex(STS_MULTI_RCCL) -- sharding, ncclAllGather of the counts, ncclSend / grouped ncclRecv of the PCM "
+                              "and the one download all inside libsummertts_hip.so",
+                      "gather_mode": md.gather_mode(), "rccl_ranks": md.rccl_ranks(), "devices": devices,
+                      "gather_ms_per_step_rank0": gms / steps, "samples_per_device": per_dev,
+                      "utterances_per_device": [slot.count(k) for k in range(N)],
+                      "rccl_library": fake or "librccl.so.1"},
+        "roofline": None, "cpu_baseline": None,
+        "note": "roofline / cpu_baseline: see the N = 1 line (sts_multi does not expose per-engine profiles)",
+    }
+    md.close()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def _env_conv_math() -> str:
     """STS_CONV_MATH as the engine reads it (f32 / fp32 / 1 = exact-fp32 MFMA, bf16x3 / 0 = split-bf16, anything else = two-term fp16)."""
     v = os.environ.get("STS_CONV_MATH", "")
@@ -281,6 +431,13 @@ def main():
                          "fp32 product, fp32 accumulation; bf16x3 = fp32 operands split exactly into three bf16 terms, six bf16 MFMA products; "
                          "f32 = the exact-fp32 MFMA.  One set of parity tolerances for all three; the line carries a timed leg of each")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed leg on the exact-fp32 MFMA path")
+    ap.add_argument("--configs-block", default="auto", choices=["auto", "on", "off"],
+                    help="append `configs`: BASELINE configs[2] (32 HiFi-GAN utterances) and configs[4] (64 MB-iSTFT utterances: the iSTFT / PQMF path) "
+                         "measured in the same process at 5 steps each, with the parity of their shortest utterance against the compiled reference.  "
+                         "auto = on for the default configs[1] run on one GPU")
+    ap.add_argument("--multi", default="torch", choices=["torch", "native"],
+                    help="--gpus N > 1: torch = one process per GPU, torch.distributed gather (the default, what a launcher starts); native = ONE process, "
+                         "sts_multi_create_ex(devices 0..N-1, STS_MULTI_RCCL): the library's own RCCL gather, the code a C++ caller gets")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
                     help="lab use: sts_debug_set on the timed engine, e.g. tile_claim=0 (A/B of a dispatch choice in one process / on one box)")
     ap.add_argument("--pipeline-engines", type=int, default=2,
@@ -295,6 +452,10 @@ def main():
         pz = CONFIG_PRESETS[args.config]
         args.workload, args.batch, args.phonemes, args.ragged = pz["workload"], pz["batch"], pz["phonemes"], pz["ragged"]
 
+    if args.multi == "native":
+        if int(os.environ.get("RANK", "0")) != 0:      # (started under a launcher: rank 0 drives all devices, the other ranks have nothing to do)
+            sys.exit(0)
+        sys.exit(native_multi_bench(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -415,7 +576,13 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    syn.set_profiling(True)
+    # the timed steps record only the two HIP events that bracket the matrix-core region (the dominant kernel family, timed inside the timed
+    # region as the contract asks); the per-stage breakdown comes from a separate leg below -- each stage event is a barrier packet between
+    # two kernels and the eight of them cost the step ~20-30 us
+    try:
+        syn.set_profiling(2)
+    except Exception:
+        syn.set_profiling(True)
     gather_busy[0] = 0.0
     gathered[0] = 0
     sync()
@@ -454,6 +621,49 @@ def main():
         sustained = {"seconds": se, "steps": ns, "ms_per_step": 1e3 * se / max(1, ns), "value": ssamp / se, "unit": "samples/s",
                      "x_realtime_16khz": ssamp / se / 16000.0,
                      "note": "back-to-back steps right after the K timed ones, same process, same engine; `value` of the line stays the K-step figure the contract defines"}
+
+    # ---- stage breakdown: the same step with all eight stage events on (untimed for the headline)
+    stage_acc, stage_steps, stage_wall = dict(acc), max(1, args.steps), elapsed
+    if not stub:
+        syn.set_profiling(True)
+        step()
+        drain()
+        sync()
+        stage_acc, stage_steps = {}, max(5, args.steps // 2)
+        tb0 = time.perf_counter()
+        for _ in range(stage_steps):
+            step()
+            for k, v in syn.profile().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + float(v)
+        drain()
+        sync()
+        stage_wall = time.perf_counter() - tb0
+
+    # ---- the reference's call shape: sts_infer_ids -- fresh argument arrays, a malloc'd copy of the PCM per call -- on four
+    # DIFFERENT utterances of the step's length in rotation, launch-ahead off (its memo would hit on a repeated request): what a caller of
+    # the drop-in API gets per call when nothing repeats
+    api_leg = None
+    if dist is None and not stub and len(ids) == 1 and hasattr(syn, "infer_ids"):
+        syn.set_profiling(False)
+        syn.debug_set("launch_ahead", 0)
+        rot = [sb.synthetic_ids(len(ids[0]), cfg.vocab, salt=100 + q) for q in range(4)]
+        for q in range(4):
+            syn.infer_ids(rot[q], sid[0], ls[0])
+        n_api = max(8, args.steps)
+        la, sa = [], 0
+        torch.cuda.synchronize()
+        ta0 = time.perf_counter()
+        for q in range(n_api):
+            tq = time.perf_counter()
+            sa += int(syn.infer_ids(rot[q % 4], sid[0], ls[0]).size)
+            la.append(time.perf_counter() - tq)
+        ta = time.perf_counter() - ta0
+        api_leg = {"calls": n_api, "ms_per_call": 1e3 * ta / n_api, "p50_latency_ms": 1e3 * float(np.median(la)), "value": sa / ta, "unit": "samples/s",
+                   "x_realtime_16khz": sa / ta / 16000.0,
+                   "note": "sts_infer_ids per call (argument arrays built per call, PCM copied into caller-owned memory), four different utterances of the "
+                           "step's length in rotation, launch-ahead disabled: no call repeats a request, every call waits for its frame count"}
+        syn.debug_set("launch_ahead", 1)
+        syn.set_profiling(True)
 
     # the utterance of the step that the reference is run on (CPU baseline + parity)
     cpu_u = 0
@@ -593,9 +803,9 @@ def main():
                                     ("duration", "ms_duration", "flops_duration", "bytes_duration"),
                                     ("flow", "ms_flow", "flops_flow", "bytes_flow"),
                                     ("decoder", "ms_decoder", "flops_decoder", "bytes_decoder_min")):
-            ms = acc.get(kms, 0.0) / steps
-            fl = acc.get(kfl, 0.0) / steps
-            by = acc.get(kby, 0.0) / steps
+            ms = stage_acc.get(kms, 0.0) / stage_steps          # (from the separate leg with all stage events on)
+            fl = stage_acc.get(kfl, 0.0) / stage_steps
+            by = stage_acc.get(kby, 0.0) / stage_steps
             t_hbm = by / (PEAK_HBM_GBS * 1e9) * 1e3
             t_mfma = fl / ((peak_tf if name == "decoder" else PEAK_F32_MFMA_TFLOPS) * 1e12) * 1e3
             bound_ms = max(t_hbm, t_mfma)
@@ -617,8 +827,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": (("f32 (decoder trunk convs: fp32 operands as 2 fp16 terms = 22-23 of their 24 mantissa bits, 3 fp16 MFMA products per fp32 "
-                       "product, f32 accumulation -- measured error in `parity`, same tolerance as the exact-fp32 leg; everything else f32)")
+            "dtype": (("f32 (decoder trunk convs AND the reverse flow's WaveNet convs (wn_flow.hip, one-utterance calls): fp32 operands as 2 fp16 terms = "
+                       "22-23 of their 24 mantissa bits, 3 fp16 MFMA products per fp32 product, f32 accumulation -- measured error in `parity`, same "
+                       "tolerance as the exact-fp32 leg; batches additionally run the flow / text-encoder / conv_pre convs in this form from ~384 workgroups per launch on; "
+                       "everything else -- attention, LayerNorm, duration predictor, splines, tails -- plain f32)")
                       if args.conv_math == "f16x2" else
                       ("f32 (decoder trunk convs: fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per fp32 product, "
                        "f32 accumulation; everything else f32)")) if split else "f32",
@@ -635,10 +847,13 @@ def main():
                 "kernel_build_id": build_id, "conv_math": args.conv_math,
             },
             "stage_ms_per_step": {k: stages[k]["ms"] for k in ("text_encoder", "duration", "flow", "decoder")},
+            "stage_breakdown_leg": {"steps": stage_steps, "ms_per_step": 1e3 * stage_wall / stage_steps,
+                                    "note": "stage_ms_per_step / roofline_stages come from this separate leg (all eight stage events recorded: each is a barrier "
+                                            "packet between two kernels); the K timed steps record only the two events around the matrix-core region"},
             "host_sync_wait_ms_per_step": acc.get("ms_sync_wait_host", 0.0) / steps,
             "host_us_per_step": {"setup_to_first_launch": acc.get("us_host_setup", 0.0) / steps, "entry_to_last_launch": acc.get("us_host_enqueue", 0.0) / steps,
                                  "after_last_sync": acc.get("us_host_tail", 0.0) / steps,
-                                 "step_wall_minus_device_stages": 1e3 * (1e3 * elapsed / steps - sum(stages[k]["ms"] for k in ("text_encoder", "duration", "flow", "decoder"))),
+                                 "step_wall_minus_device_stages": 1e3 * (1e3 * stage_wall / stage_steps - sum(stages[k]["ms"] for k in ("text_encoder", "duration", "flow", "decoder"))),
                                  "pcm": "view of the engine's pinned download buffer (sts_pcm_host_view)" if prepared is not None and dist is None else "copied / gathered"},
             "roofline": {
                 "kernel": ("conv_bf3_kernel + conv_bf3_group_kernel + resblock_bf3_kernel (decoder upsamplers + grouped / fused ResBlock convs, "
@@ -698,6 +913,14 @@ def main():
             out["request_pool"] = pipelined
         if sustained is not None:
             out["sustained"] = sustained
+        if api_leg is not None:
+            out["api_call_leg"] = api_leg
+        want_cfgs = args.configs_block == "on" or (args.configs_block == "auto" and world == 1 and dist is None and not stub
+                                                   and config_label(args) == CONFIG_PRESETS[1]["label"])
+        if want_cfgs and not stub:
+            # configs[2] and configs[4] in the driver's own line: the 32-utterance HiFi-GAN batch and the 64-utterance
+            # MB-iSTFT batch (iSTFT + PQMF path), 5 timed steps each, parity of the shortest utterance against the compiled reference
+            out["configs"] = {f"configs[{n_}]": measure_config(eng, torch, n_, args.conv_math, with_cpu=not args.no_cpu_baseline) for n_ in (2, 4)}
         if world == 1 and not args.no_cpu_baseline and not stub:
             try:
                 cpu_T = args.cpu_sample_phonemes or (len(ids[cpu_u]) if ids else args.phonemes)

@@ -171,7 +171,7 @@ int sts_set_profiling(sts_engine* e, int enable);
  * sizeof(sts_profile)) bytes, so a client compiled against an older header passes ITS sizeof and is never overrun;
  * sts_get_profile(e, p) == sts_get_profile_ex(e, p, sizeof(sts_profile)) of the header this library was built from -- use it only
  * when client and library are built together. */
-#define STS_ABI_VERSION 6
+#define STS_ABI_VERSION 7
 int sts_abi_version(void);
 /* bit 0: lab build (-DSTS_EXPERIMENTS: environment knobs of knobs.hpp, every conv tile code);
  * 0 for the shipped library */
@@ -234,6 +234,13 @@ int sts_multi_create(const float* blob, int64_t blob_bytes, const int32_t* devic
 enum { STS_MULTI_AUTO = 0, STS_MULTI_RCCL = 1, STS_MULTI_DOWNLOAD = 2 };
 int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* devices, int32_t n_devices, int32_t flags, sts_multi** out);
 int sts_multi_gather_mode(const sts_multi* m);
+/*   sts_multi_rccl_ranks: the size of the handle's communicator as RCCL reports it (ncclCommCount; 0 = no RCCL gather on this handle,
+ *   -1 = the RCCL library has no ncclCommCount).  sts_multi_last_gather_ms: wall time rank 0 spent inside the last call's RCCL gather
+ *   (count exchange, ready round, transfers, the one download; 0 in download mode).  sts_multi_set_conv_math: sts_set_conv_math on
+ *   every engine of the handle. */
+int sts_multi_rccl_ranks(sts_multi* m);
+double sts_multi_last_gather_ms(const sts_multi* m);
+int sts_multi_set_conv_math(sts_multi* m, int mode);
 /*   test hook: the shared library that provides the nccl* entry points (NULL / "" = librccl.so.1) and whether STS_MULTI_RCCL may list
  *   one device several times (tests/fake_rccl: N emulated ranks on one GPU; real RCCL refuses duplicates).  Only before the first
  *   STS_MULTI_RCCL handle of the process is created.  TEST-ONLY: refused with STS_ESTATE unless the process environment carries

@@ -59,6 +59,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;   // optional (sts_multi_rccl_ranks)
     std::string err;
     std::string override_path; bool allow_repeated = false;   // sts_multi_set_rccl_library (test hook)
     bool load() {
@@ -72,6 +73,7 @@ struct Rccl {
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");
+        CommCount = (decltype(CommCount))dlsym(h, "ncclCommCount");
         return CommInitAll && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd && GetErrorString;
     }
 };
@@ -103,6 +105,7 @@ struct sts_multi {
     int16_t* h_gather = nullptr; size_t h_gather_cap = 0;    // pinned
     std::vector<int64_t> counts, offsets; int64_t gather_total = 0;
     bool rccl_broken = false;               // a collective failed or timed out: communicators aborted, downloads from the next call on
+    double last_gather_ms = 0;              // rank 0's wall time inside the last call's gather: counts -> ready round -> transfers -> the one download
     static constexpr int kCollectiveTimeoutMs = 60000;
 
     // Who may touch comms[k] (round 5): every RCCL host call of rank k goes through rccl_call(k, ...), which takes the
@@ -171,6 +174,9 @@ struct sts_multi {
         Engine& eng = *engines[k];
         Rccl& R = rccl();
         const int nd = (int)engines.size();
+        const auto tg0 = std::chrono::steady_clock::now();
+        struct GatherClock { sts_multi* m; int k; std::chrono::steady_clock::time_point t0;
+                             ~GatherClock() { if (k == 0) m->last_gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } gclock{this, k, tg0};
         const long long mine = sh.rc == STS_OK && !sh.utt.empty() ? (long long)eng.total_samples : 0;    // a failed shard still takes part
         auto ck = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess) { if (sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + (broken() ? "the communicators were aborted by a peer's failure" : R.GetErrorString(r)); } abort_all(); } return r == ncclSuccess; };
         auto hk = [&](hipError_t e, const char* what) { if (e != hipSuccess && sh.rc == STS_OK) { sh.rc = STS_EDEVICE; sh.err = std::string(what) + ": " + hipGetErrorString(e); } return e == hipSuccess; };
@@ -322,6 +328,24 @@ int64_t sts_multi_gather_layout(const int64_t* counts, int32_t n_ranks, int64_t*
 }
 
 int sts_multi_gather_mode(const sts_multi* m) { return m ? m->gather_mode : 0; }
+
+// the size of the handle's communicator as RCCL itself reports it (ncclCommCount on rank 0's communicator); 0: no RCCL gather on this
+// handle (download mode, or the communicators were aborted), -1: the library does not export ncclCommCount
+int sts_multi_rccl_ranks(sts_multi* m) {
+    if (!m || m->gather_mode != 1 || m->comms.empty()) return 0;
+    Rccl& R = rccl();
+    if (!R.CommCount) return -1;
+    int n = 0;
+    const ncclResult_t r = m->rccl_call(0, [&](ncclComm_t cm) { return R.CommCount(cm, &n); });
+    return r == ncclSuccess ? n : 0;
+}
+double sts_multi_last_gather_ms(const sts_multi* m) { return m ? m->last_gather_ms : 0.0; }
+int sts_multi_set_conv_math(sts_multi* m, int mode) {
+    if (!m) return multi_err(STS_EINVAL, "null handle");
+    if (mode < 0 || mode > 3) return multi_err(STS_EINVAL, "conv math must be 0..3");
+    for (auto& e : m->engines) { e->conv_math = mode; e->h2_disabled = false; e->h2_consecutive = 0; }
+    return STS_OK;
+}
 
 // Test hook: the shared library that provides the nccl* entry points (default: librccl.so.1) and whether STS_MULTI_RCCL may list a
 // device more than once (real RCCL refuses that; tests/fake_rccl emulates N ranks on ONE GPU).  Takes effect for handles created

@@ -118,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack", "sts_debug_set", "sts_multi_create_ex", "sts_multi_gather_mode", "sts_multi_gather_layout",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
     "sts_multi_create", "sts_multi_destroy", "sts_multi_device_count", "sts_multi_speaker_num", "sts_multi_infer_ids_batch",
-    "sts_multi_shard_of", "sts_multi_last_error", "sts_multi_set_rccl_library", "sts_get_profile_ex", "sts_abi_version", "sts_build_flags",
+    "sts_multi_shard_of", "sts_multi_last_error", "sts_multi_set_rccl_library", "sts_multi_rccl_ranks", "sts_multi_last_gather_ms", "sts_multi_set_conv_math", "sts_get_profile_ex", "sts_abi_version", "sts_build_flags",
 ]
 
 
@@ -421,6 +421,22 @@ class MultiDevice:
 
     def gather_mode(self) -> str:
         return "rccl" if int(self.lib.sts_multi_gather_mode(self.h)) == 1 else "download"
+
+    def rccl_ranks(self) -> int:
+        """Size of the handle's communicator as RCCL reports it (ncclCommCount); 0 without an RCCL gather."""
+        self.lib.sts_multi_rccl_ranks.argtypes = [C.c_void_p]
+        return int(self.lib.sts_multi_rccl_ranks(self.h))
+
+    def last_gather_ms(self) -> float:
+        self.lib.sts_multi_last_gather_ms.argtypes = [C.c_void_p]
+        self.lib.sts_multi_last_gather_ms.restype = C.c_double
+        return float(self.lib.sts_multi_last_gather_ms(self.h))
+
+    def set_conv_math(self, mode):
+        m = {"bf16x3": 0, "f32": 1, "bf16x3_all": 2, "f16x2": 3}.get(mode, mode)
+        self.lib.sts_multi_set_conv_math.argtypes = [C.c_void_p, C.c_int]
+        if self.lib.sts_multi_set_conv_math(self.h, int(m)) != 0:
+            raise StsError(f"sts_multi_set_conv_math: {self.lib.sts_multi_last_error().decode()}")
 
     @staticmethod
     def set_rccl_library(path: Optional[str], allow_repeated_devices: bool = False):

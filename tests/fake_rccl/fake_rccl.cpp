@@ -110,6 +110,11 @@ ncclResult_t ncclCommAbort(ncclComm_t comm) {
     // (nothing is freed: peer threads may still be inside a call on this world -- a test library can afford the leak)
     return ncclSuccess;
 }
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = ((Comm*)comm)->w->n;
+    return ncclSuccess;
+}
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : (r == ncclInvalidArgument ? "fake rccl: invalid argument / unmatched transfer" : "fake rccl: aborted or injected failure"); }
 
 static bool barrier(World* w, std::unique_lock<std::mutex>& lk) {

@@ -39,3 +39,36 @@ class Synthesizer:
 
     def close(self):
         pass
+
+
+class MultiDevice:
+    """Stand-in for engine.MultiDevice (`bench.py --multi native`): utterances dealt round-robin, the same ramp PCM as above."""
+    _fake = None
+
+    def __init__(self, blob, devices, gather="auto"):
+        self.devices = list(devices)
+        self.gather = gather
+        self.h = None
+        self.lib = None
+
+    @staticmethod
+    def set_rccl_library(path, allow_repeated_devices=False):
+        MultiDevice._fake = path
+
+    def gather_mode(self):
+        return "rccl" if self.gather == "rccl" else "download"
+
+    def rccl_ranks(self):
+        return len(self.devices) if self.gather == "rccl" else 0
+
+    def last_gather_ms(self):
+        return 0.25
+
+    def shard_of(self, lengths):
+        return np.asarray([u % len(self.devices) for u in range(len(lengths))], np.int32)
+
+    def infer_batch(self, ids, sid=None, length_scale=None):
+        return [(np.arange(len(a) * 100, dtype=np.int64) + int(a[0])).astype(np.int16) for a in ids]
+
+    def close(self):
+        pass

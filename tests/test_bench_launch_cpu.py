@@ -62,3 +62,15 @@ def test_config_presets_name_the_baseline_config_they_form():
     out = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "5", "--phonemes", "33"],
                {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": "29644"})
     assert out["config"]["baseline_config"] is None and out["config"]["workload"].startswith("custom")
+
+
+def test_multi_native_runs_in_one_process_and_reports_the_communicator():
+    """`bench.py --gpus N --multi native`: ONE process drives all devices through sts_multi's own RCCL gather; the line
+    carries the communicator size as RCCL reports it and rank 0's gather time.  Here: the plumbing with the stub engine (the real library
+    runs it against tests/fake_rccl on the GPU box: tests/test_parity_gpu.py)."""
+    out = _run(["--gpus", "3", "--multi", "native", "--steps", "2", "--warmup", "1", "--batch", "2", "--phonemes", "10"])
+    assert out["n_gpus"] == 3 and out["scaling"] == "weak" and out["config"]["launched_by"].startswith("bench.py --multi native")
+    mg = out["multi_gpu"]
+    assert mg["rccl_ranks"] == 3 and mg["gather_mode"] == "rccl" and sum(mg["utterances_per_device"]) == 6
+    assert sum(mg["samples_per_device"]) == 2 * 6 * 1000 and abs(mg["gather_ms_per_step_rank0"] - 0.25) < 1e-9
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 2 - 2 * 6 * 1000) < 1.0

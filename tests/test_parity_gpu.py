@@ -1095,6 +1095,31 @@ def test_multi_device_rccl_gather_with_three_emulated_ranks():
     assert len(res["checks"]) >= 12
 
 
+def test_bench_multi_native_drives_the_library_gather_with_three_emulated_ranks():
+    """`bench.py --gpus 3 --multi native`: one process, sts_multi_create_ex(STS_MULTI_RCCL) -- here with device 0 listed three
+    times against tests/fake_rccl (the only N > 1 a one-GPU box can offer).  The line must carry the communicator size as the RCCL library reports
+    it (ncclCommCount), a gather time, and the samples of all three ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = os.path.join(root, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True)
+    env = dict(os.environ, STS_TEST_HOOKS="1", STS_BENCH_RCCL_LIB=fake, STS_BENCH_TINY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--multi", "native", "--share-gpu", "--steps", "3", "--warmup", "1",
+                        "--batch", "2", "--phonemes", "21"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = out["multi_gpu"]
+    assert out["n_gpus"] == 3 and mg["gather_mode"] == "rccl" and mg["rccl_ranks"] == 3, mg
+    assert mg["utterances_per_device"] == [2, 2, 2] and all(s > 0 for s in mg["samples_per_device"]) and mg["gather_ms_per_step_rank0"] > 0
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 3 - sum(mg["samples_per_device"])) < 1.0
+
+
 def test_concurrent_engines_on_one_gpu_return_the_reference_result():
     """Three engines on ONE GPU driven from three host threads at the same time (what sts_pool does), twenty calls each, on the bench's
     own utterance: every call must return, bit for bit, what the engine returns when it runs alone -- and THAT result is pinned to the
