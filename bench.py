@@ -431,6 +431,9 @@ def main():
                          "fp32 product, fp32 accumulation; bf16x3 = fp32 operands split exactly into three bf16 terms, six bf16 MFMA products; "
                          "f32 = the exact-fp32 MFMA.  One set of parity tolerances for all three; the line carries a timed leg of each")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra timed leg on the exact-fp32 MFMA path")
+    ap.add_argument("--timed-profiling", type=int, default=2, choices=[0, 1, 2],
+                    help="HIP events recorded inside the K timed steps: 2 (default) = the two around the matrix-core region (the roofline's kernel time), "
+                         "1 = all eight stage events, 0 = none (lab A/B of what the events cost; the roofline then comes from the stage-breakdown leg)")
     ap.add_argument("--configs-block", default="auto", choices=["auto", "on", "off"],
                     help="append `configs`: BASELINE configs[2] (32 HiFi-GAN utterances) and configs[4] (64 MB-iSTFT utterances: the iSTFT / PQMF path) "
                          "measured in the same process at 5 steps each, with the parity of their shortest utterance against the compiled reference.  "
@@ -580,7 +583,7 @@ def main():
     # region as the contract asks); the per-stage breakdown comes from a separate leg below -- each stage event is a barrier packet between
     # two kernels and the eight of them cost the step ~20-30 us
     try:
-        syn.set_profiling(2)
+        syn.set_profiling(args.timed_profiling)
     except Exception:
         syn.set_profiling(True)
     gather_busy[0] = 0.0
@@ -790,10 +793,13 @@ def main():
     if rank == 0:
         steps = max(1, args.steps)
         value = total_samples / elapsed
-        mfma_ms, launches = acc.get("ms_decoder_mfma", 0.0), acc.get("decoder_mfma_launches", 0.0)
-        achieved_tf = (acc.get("flops_decoder_mfma", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
-        issued_tf = (acc.get("flops_decoder_mfma_executed", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
-        bf16_tf = (acc.get("flops_decoder_bf16_issued", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        racc, rsteps = acc, steps
+        if args.timed_profiling == 0:           # (lab A/B: no events in the timed steps -- the kernel time of the roofline comes from the stage leg)
+            racc, rsteps = stage_acc, stage_steps
+        mfma_ms, launches = racc.get("ms_decoder_mfma", 0.0), racc.get("decoder_mfma_launches", 0.0)
+        achieved_tf = (racc.get("flops_decoder_mfma", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        issued_tf = (racc.get("flops_decoder_mfma_executed", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
+        bf16_tf = (racc.get("flops_decoder_bf16_issued", 0.0) / (mfma_ms * 1e-3)) / 1e12 if mfma_ms > 0 else 0.0
         split = bf16_tf > 0.0                       # the trunk ran on split operands (conv_bf3.hip)
         products = 3 if args.conv_math == "f16x2" else BF16_PRODUCTS_PER_F32      # 16-bit matrix products per fp32 product
         peak_tf = PEAK_BF16_MFMA_TFLOPS / products if split else PEAK_F32_MFMA_TFLOPS
@@ -888,11 +894,11 @@ def main():
                 "mfma_issued_definition": "exact-fp32 matrix-core FLOPs executed by launches on the fp32 MFMA path (0 when the whole trunk runs "
                                           "on split operands; with --conv-math f32 the Winograd-domain layer kernels need (4 n3 + 3 n2) / (2 k) of "
                                           "a k-tap conv's products)",
-                "algorithmic_bytes_per_launch": acc.get("bytes_decoder_min", 0.0) / max(1.0, launches),
-                "launches_per_step": launches / steps,
+                "algorithmic_bytes_per_launch": racc.get("bytes_decoder_min", 0.0) / max(1.0, launches),
+                "launches_per_step": launches / rsteps,
                 "avg_launch_us": 1e3 * mfma_ms / max(1.0, launches),
-                "algorithmic_gflop_per_step": acc.get("flops_decoder_mfma", 0.0) / steps / 1e9,
-                "decoder_min_hbm_gb_per_step": acc.get("bytes_decoder_min", 0.0) / steps / 1e9,
+                "algorithmic_gflop_per_step": racc.get("flops_decoder_mfma", 0.0) / rsteps / 1e9,
+                "decoder_min_hbm_gb_per_step": racc.get("bytes_decoder_min", 0.0) / rsteps / 1e9,
             },
             "roofline_stages": stages,
         }

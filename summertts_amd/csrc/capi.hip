@@ -160,7 +160,7 @@ int sts_debug_set(sts_engine* e, int key, int value) {
     switch (key) {
         case STS_DBG_ATTN_BLOCK_MIN_WGS: if (value < 1) return set_err(STS_EINVAL, "threshold must be >= 1"); e->eng.attn_block_min_wgs = value; return STS_OK;
         case STS_DBG_FLOW_FUSED: e->eng.flow_fused = value != 0; return STS_OK;
-        case STS_DBG_LAUNCH_AHEAD: if (value < 0 || value > 2) return set_err(STS_EINVAL, "launch_ahead must be 0, 1 or 2"); if ((value == 2) != (e->eng.launch_ahead == 2)) e->eng.seen_tf_.clear(); e->eng.launch_ahead = value; return STS_OK;
+        case STS_DBG_LAUNCH_AHEAD: if (value < 0 || value > 2) return set_err(STS_EINVAL, "launch_ahead must be 0, 1 or 2"); if ((value == 2) != (e->eng.launch_ahead == 2)) { e->eng.seen_tf_.clear(); e->eng.seen_order_.clear(); } e->eng.launch_ahead = value; return STS_OK;
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
         case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
         case STS_DBG_PCM_DIRECT: e->eng.pcm_direct = value != 0; return STS_OK;

@@ -364,7 +364,8 @@ struct Engine::RunCtx {
     // Fld = the count rounded up to a bucket of 64 frames, so that a call which launches the flow and the decoder AHEAD of the frame count
     // (ahead: the count is predicted, the kernels read the real one from device memory) makes exactly the dispatch decisions of a call
     // that waited for it -- and returns bit-identical samples.  Batches: Fld == Ftot, nothing changes.
-    long Fld = 0; int maxFld = 0; bool ahead = false, mapped = false, forced = false; unsigned long long req_key = 0;
+    long Fld = 0; int maxFld = 0; bool ahead = false, ahead_b = false, mapped = false, forced = false;
+    std::vector<unsigned long long> req_keys; std::vector<long> predF;      // launch-ahead memo: per-utterance request hashes, remembered frame counts (empty: not all known)
     int halo = 0; long Wcap = 0; int upS = 1; long Lsb = 0; int sbC = 0;
     bool use_ff = false; int ffG = 0;
 };
@@ -635,21 +636,36 @@ int Engine::run_durations(RunCtx& c) {
     // 63 frames of bucket padding the waiting path also carries, never a miss; any other request takes the waiting path.  Should the
     // count land in another 64-frame bucket than predicted (a hash collision), the two stages are repeated the waiting way, so the samples a
     // request returns never depend on what the engine served before (dispatch decisions are taken per bucket).
+    // Batches (round 5): the memo is per UTTERANCE.  When every member of a packed batch has been served before, the frame
+    // geometry of the whole batch is known on the host before the duration predictor has run: the tables the batched kernels read are
+    // uploaded from the memo, flow + decoder are enqueued right behind the durations kernel, and the counts that kernel wrote are compared
+    // with the memo after the run's one stream synchronisation (a difference = a hash collision: the two stages are repeated the waiting
+    // way).  Identical geometry => identical launches => bit-identical PCM; the host -- a pool or multi-device worker -- no longer
+    // spins through the text encoder and the duration predictor.
     long pred = 0;
-    c.req_key = 0;
-    if (B == 1) {
+    c.req_keys.assign(B, 0ull);
+    for (int b = 0; b < B; b++) {
         unsigned long long h = 1469598103934665603ull;
         auto mix = [&h](unsigned v) { for (int q = 0; q < 4; q++) { h ^= (v >> (8 * q)) & 0xffu; h *= 1099511628211ull; } };
-        mix((unsigned)Ttot);
+        mix((unsigned)c.n[b]);
         if (launch_ahead != 2) {          // (2: test mode -- the key is the phoneme count alone, i.e. every request of a length collides)
-            mix((unsigned)c.sid[0]); { unsigned u; memcpy(&u, &c.ls[0], 4); mix(u); }
-            for (long t = 0; t < Ttot; t++) mix((unsigned)c.ids[0][t]);
+            mix((unsigned)(c.sid ? c.sid[b] : 0)); { const float lsb = c.ls ? c.ls[b] : 1.0f; unsigned u; memcpy(&u, &lsb, 4); mix(u); }
+            for (int t = 0; t < c.n[b]; t++) mix((unsigned)c.ids[b][t]);
         }
-        c.req_key = h | 1ull;
+        c.req_keys[b] = h | 1ull;
     }
-    if (launch_ahead && B == 1 && !ss && !have_forced && !record_taps && mapped)
-        for (const auto& tf : seen_tf_) if (tf.first == c.req_key) pred = tf.second;
+    c.predF.clear();
+    if (launch_ahead && !ss && !have_forced && !record_taps && mapped) {
+        c.predF.resize(B);
+        for (int b = 0; b < B; b++) {
+            const auto it = seen_tf_.find(c.req_keys[b]);
+            if (it == seen_tf_.end()) { c.predF.clear(); break; }
+            c.predF[b] = it->second;
+        }
+    }
+    if (B == 1 && !c.predF.empty()) pred = c.predF[0];
     c.ahead = pred > 0;
+    c.ahead_b = B > 1 && !c.predF.empty();
     c.hop = M.hop_total;
     const long cap = c.ahead ? (pred + 63) / 64 * 64 : 0;
     durations(r_final, M.dur_type == 0 ? 1 : 0, M.ea_m, M.ea_logs, bt.ls, have_forced ? bt.forced : nullptr, bt.dlogw,
@@ -661,6 +677,14 @@ int Engine::run_durations(RunCtx& c) {
     sync_wait_ms_ = 0;
     if (c.ahead) {
         c.Ftot = cap; c.maxF = (int)cap;                // (capacity; the real count replaces it in run_output)
+        return frame_geometry(c);
+    }
+    if (c.ahead_b) {                                    // the batch's geometry from the memo; checked against the kernel's counts in run_output
+        c.Ftot = 0; c.maxF = 0;
+        for (int b = 0; b < B; b++) {
+            const int f = (int)c.predF[b];
+            c.p_offF[b] = (int)c.Ftot; c.p_lenF[b] = f; c.Ftot += f; if (f > c.maxF) c.maxF = f;
+        }
         return frame_geometry(c);
     }
     int rc = wait_frame_counts(c);
@@ -710,11 +734,14 @@ int Engine::wait_frame_counts(RunCtx& c) {
         int f = p_down[Ttot + b];
         p_offF[b] = (int)c.Ftot; p_lenF[b] = f; c.Ftot += f; if (f > c.maxF) c.maxF = f;
     }
-    if (B == 1 && c.req_key && !c.forced) {      // the memo of run_durations: this request's frame count (replaces, never a running maximum)
-        bool found = false;
-        for (auto& tf : seen_tf_) if (tf.first == c.req_key) { tf.second = c.Ftot; found = true; }
-        if (!found) { if (seen_tf_.size() >= 64) seen_tf_.erase(seen_tf_.begin()); seen_tf_.emplace_back(c.req_key, c.Ftot); }
-    }
+    if (!c.forced && (int)c.req_keys.size() == B)      // the memo of run_durations: every utterance's frame count (replaces, never a running maximum)
+        for (int b = 0; b < B; b++) {
+            const auto it = seen_tf_.find(c.req_keys[b]);
+            if (it != seen_tf_.end()) { it->second = p_lenF[b]; continue; }
+            if (seen_order_.size() >= kMemoEntries) { seen_tf_.erase(seen_order_.front()); seen_order_.pop_front(); }
+            seen_tf_.emplace(c.req_keys[b], (long)p_lenF[b]);
+            seen_order_.push_back(c.req_keys[b]);
+        }
     return STS_OK;
 }
 
@@ -1192,7 +1219,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             if (wave) HIPCK(hipMemcpyAsync(wave, tm, (size_t)Ntot * 4, hipMemcpyDeviceToDevice, stream));
         } else {
             const Lvl lo = lvF(S * 16, 0);
-            synth_fir(tm, ltm.ld, ltm.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, wave, bf.pcm, lo.seg, nw,
+            synth_fir(tm, ltm.ld, ltm.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, M.dec_type == 1 ? M.fir_bias : 0.f, wave, bf.pcm, lo.seg, nw,
                       ltm.max_len, stream);
         }
         flops_[3] += 2.0 * (double)Ntot * (16.0 * 4 + 4 * 18 * 4 / 4.0);
@@ -1320,6 +1347,25 @@ int Engine::run_output(RunCtx& c) {
             HIPCK(hipStreamSynchronize(stream));
             host_t_sync_ = now_us();
         }
+        if (c.ahead_b) {
+            // a batch launched from the memo: the counts the durations kernel wrote (already on the host) must be the remembered ones
+            const std::vector<long> pred = c.predF;
+            int rc = wait_frame_counts(c);
+            if (rc != STS_OK) return rc;
+            bool same = true;
+            for (int b = 0; b < B; b++) same = same && p_lenF[b] == (int)pred[b];
+            c.ahead_b = false;
+            if (!same) {
+                ahead_misses++;
+                flops_[2] = flops_[3] = bytes_[2] = bytes_[3] = bytes_w_[2] = bytes_w_[3] = 0;
+                mfma_flops_ = 0; mfma_exec_ = 0; bf16_exec_ = 0; mfma_launches_ = 0; in_mfma_region_ = false;
+                if ((rc = frame_geometry(c)) != STS_OK) return rc;
+                if ((rc = run_frame_workspace(c)) != STS_OK) return rc;
+                if ((rc = run_flow(c)) != STS_OK) return rc;
+                return run_output(c);
+            }
+            prof.launch_ahead = 1;
+        }
         HIPCK(hipGetLastError());
     } else {
         // Streaming: chunk c = frames [f0, f1) is decoded from the window [f0 - halo, f1 + halo)
@@ -1370,7 +1416,7 @@ int Engine::run_output(RunCtx& c) {
     prof.flops_decoder_mfma_executed = mfma_exec_; prof.flops_decoder_bf16_issued = bf16_exec_;
     prof.conv_math_fallbacks = h2_fallbacks; prof.conv_math_pinned = h2_disabled ? 1 : 0;
     prof.bytes_text_encoder = bytes_[0]; prof.bytes_duration = bytes_[1]; prof.bytes_flow = bytes_[2];
-    prof.ms_sync_wait_host = (float)sync_wait_ms_; prof.launch_ahead = ahead ? 1 : 0; prof.launch_ahead_misses = ahead_misses;
+    prof.ms_sync_wait_host = (float)sync_wait_ms_; prof.launch_ahead = (ahead || prof.launch_ahead == 1) ? 1 : 0; prof.launch_ahead_misses = ahead_misses;
     if (profiling == 2) {
         float t = 0;
         (void)hipEventElapsedTime(&t, ev_[5], ev_[6]); prof.ms_decoder_mfma = t;

@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <deque>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -89,7 +91,10 @@ public:
     int attn_block_min_wgs = 96;       // attention_mfma_kernel from this many workgroups on (sts_debug_set)
     int launch_ahead = 1;              // 1: a one-utterance call the engine has served before enqueues flow + decoder before the frame count is on the host; 2 (tests): the memo is keyed by the phoneme count alone (sts_debug_set STS_DBG_LAUNCH_AHEAD)
     long ahead_misses = 0;             // launch-ahead calls whose count fell outside the predicted 64-frame bucket (a hash collision; repeated the waiting way)
-    std::vector<std::pair<unsigned long long, long>> seen_tf_;    // (hash of a one-utterance request's ids / speaker / length scale, its frame count): the launch-ahead memo, 64 entries FIFO
+    // the launch-ahead memo: hash of an utterance's (ids, speaker, length scale) -> its frame count (a pure function of them: the reference's
+    // noise scale is 0); the last kMemoEntries distinct utterances, FIFO
+    static constexpr size_t kMemoEntries = 1024;
+    std::unordered_map<unsigned long long, long> seen_tf_; std::deque<unsigned long long> seen_order_;
     int flow_fused = 1;                // 1: the reverse flow as one launch per WaveNet layer where eligible (wn_flow.hip; two-term fp16 arithmetic only);
                                        // 0: one launch per conv (sts_debug_set STS_DBG_FLOW_FUSED)
     hipStream_t stream = nullptr;

@@ -273,7 +273,7 @@ void istft_spectrum(const float* sb, long ld, int rows, float* spec, long total,
 void istft_ola(const float* spec, long ld, int bands, int band_rows, SegView seg_frames, float* tm, long tm_ld,
                SegView seg_tm, int B, int max_n, hipStream_t st);
 // polyphase synthesis FIR over the x4 zero-stuffed band signals: out[i] = sum_tau sum_b g*tm[b][(i+tau-pad)/4]*fir[tau*4+b]
-void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, int ntap, int pad, float gain,
+void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, int ntap, int pad, float gain, float bias,
                float* wave, int16_t* pcm, SegView seg_out, int B, int max_n, hipStream_t st);
 // pcm = (int16)(int32)(wave * 32737)   (SynthesizerTrn.cpp:389-396: truncation, wrap-around)
 void quantize_pcm(const float* wave, int16_t* pcm, long n, hipStream_t st);

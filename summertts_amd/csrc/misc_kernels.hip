@@ -854,7 +854,7 @@ void istft_ola(const float* spec, long ld, int bands, int band_rows, SegView seg
 // x4 zero-stuff (gain) + 63-tap synthesis FIR, polyphase: only every 4th tap meets a non-zero sample.
 // PQMF: /root/reference/src/modules/pqmf.cpp:104-115 ; MS learned filter: models/Generator_MS.cpp:225-226
 __global__ __launch_bounds__(256) void synth_fir_kernel(const float* tm, long tm_ld, SegView segt, const float* fir,
-                                                        int ntap, int pad, float gain, float* wave, int16_t* pcm,
+                                                        int ntap, int pad, float gain, float bias, float* wave, int16_t* pcm,
                                                         SegView sego) {
     const int b = blockIdx.y;
     const int n = seg_len(segt, b), N = 4 * n;
@@ -870,14 +870,15 @@ __global__ __launch_bounds__(256) void synth_fir_kernel(const float* tm, long tm
 #pragma unroll
         for (int q = 0; q < 4; q++) s += (gain * tm[(size_t)q * tm_ld + tb + t]) * fir[tau * 4 + q];
     }
+    s += bias;                 // (MS: the learned conv's bias, when the blob carries one; 0 otherwise)
     if (wave) wave[ob + i] = s;
     pcm[ob + i] = pcm_cast(s);
 }
-void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, int ntap, int pad, float gain, float* wave,
+void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, int ntap, int pad, float gain, float bias, float* wave,
                int16_t* pcm, SegView seg_out, int B, int max_n, hipStream_t st) {
     if (B <= 0 || max_n <= 0) return;
     hipLaunchKernelGGL(synth_fir_kernel, dim3((4 * max_n + 255) / 256, B), dim3(256), 0, st, tm, tm_ld, seg_tm, fir, ntap,
-                       pad, gain, wave, pcm, seg_out);
+                       pad, gain, bias, wave, pcm, seg_out);
 }
 
 __global__ void quantize_pcm_kernel(const float* wave, int16_t* pcm, long n) {

@@ -517,9 +517,11 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         if (m.dec_type == 3) { build_pqmf(fir); m.fir_taps = 63; m.fir_pad = 31; }
         else {   // MS: learned multistream conv, weights [1][k][4]
             HConv h = parse_conv(r);
-            if (!r.ok || h.out_ch != 1 || h.in_ch != 4 || h.k > 63 || h.has_bias == 1 || h.dil != 1 || 2 * h.pad != h.k - 1) FAIL("multistream_conv_post shape");
+            if (!r.ok || h.out_ch != 1 || h.in_ch != 4 || h.k > 63 || h.dil != 1 || 2 * h.pad != h.k - 1) FAIL("multistream_conv_post shape");
             memcpy(fir, h.w, sizeof(float) * (size_t)h.k * 4);
             m.fir_taps = h.k; m.fir_pad = h.pad;
+            // (upstream builds this conv without a bias; the reference's nn_conv1d honours one when the blob carries it: nn_conv1d.cpp:40-46)
+            m.fir_bias = h.has_bias == 1 && h.b ? h.b[0] : 0.f;
         }
     }
 

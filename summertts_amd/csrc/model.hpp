@@ -80,7 +80,7 @@ struct Model {
     std::vector<int> up_rate, up_k;
     DConv conv_pre, conv_post, dec_cond, ms_post;
     std::vector<DConv> ups; std::vector<DResBlock> rb;
-    const float* synth_fir = nullptr; int fir_taps = 63, fir_pad = 31;
+    const float* synth_fir = nullptr; int fir_taps = 63, fir_pad = 31; float fir_bias = 0.f;
     int hop_total = 0;
     // flow
     int n_flows = 0; std::vector<DCoupling> cp;

@@ -921,6 +921,61 @@ def test_block_attention_kernel_matches_oracle_at_every_size(kind):
     syn.close()
 
 
+@pytest.mark.parametrize("kind,size", [("ms_hifigan_sdp", "tiny"), ("mbb_fix", "tiny"), ("hifigan_sdp", "full")])
+def test_launch_ahead_for_packed_batches(kind, size):
+    """SURVEY 8 f3, finished in round 5: a packed batch whose members the engine has ALL served before (per-utterance memo: ids, speaker, length
+    scale -> frame count) is launched without the host waiting for the frame counts -- the geometry tables come from the memo, the counts the
+    durations kernel writes are checked after the run's one synchronisation.  Same geometry, same launches: the PCM is bit-identical to the
+    waiting path's, which is pinned to the oracle.  A batch with one new member waits; a wrong memo entry (test mode: keyed by length alone) is
+    detected and the two stages are repeated."""
+    cfg = sb.full_cfg(kind) if size == "full" else sb.tiny_cfg(kind)
+    blob = sb.make_blob(cfg, 17)
+    lens = [23, 9, 31, 9, 16] if size == "tiny" else [70, 64, 90]
+    ids = [sb.synthetic_ids(t, cfg.vocab, salt=3 + i) for i, t in enumerate(lens)]
+    nspk = 5 if cfg.is_ms else 1
+    sid = [i % nspk for i in range(len(ids))]
+    ls = [1.0, 1.1, 0.9, 1.0, 1.2][:len(ids)]
+    syn = engine.Synthesizer(blob)
+    syn.set_profiling(True)
+    n1 = syn.run_batch(ids, sid, ls).copy()
+    first = syn.pcm_host().copy()
+    assert syn.profile()["launch_ahead"] == 0
+    if size == "tiny":
+        port = pyref.PortModel(blob)
+        off = 0
+        for i in range(len(ids)):
+            o = port.infer_ids(ids[i], sid[i], ls[i])
+            assert_pcm_close(first[off:off + int(n1[i])], o["pcm"], f"{kind} member {i} (waiting path) vs the oracle")
+            off += int(n1[i])
+    for _ in range(2):
+        n2 = syn.run_batch(ids, sid, ls)
+        p = syn.profile()
+        assert p["launch_ahead"] == 1 and p["launch_ahead_misses"] == 0 and p["ms_sync_wait_host"] < 0.05, p
+        assert np.array_equal(n2, n1) and np.array_equal(syn.pcm_host(), first), "launch-ahead changed a sample of the batch"
+    # a member the engine has not served: the whole batch waits; a sub-batch of known members runs ahead
+    ids_new = ids[:-1] + [sb.synthetic_ids(lens[-1], cfg.vocab, salt=77)]
+    fresh = engine.Synthesizer(blob)
+    fresh.run_batch(ids_new, sid, ls)
+    want_new = fresh.pcm_host().copy()
+    syn.run_batch(ids_new, sid, ls)
+    assert syn.profile()["launch_ahead"] == 0 and np.array_equal(syn.pcm_host(), want_new)
+    fresh.run_batch(ids[1:], sid[1:], ls[1:])
+    want_sub = fresh.pcm_host().copy()
+    syn.run_batch(ids[1:], sid[1:], ls[1:])
+    assert syn.profile()["launch_ahead"] == 1 and np.array_equal(syn.pcm_host(), want_sub)
+    # a wrong memo entry (keyed by the phoneme count alone): detected after the run, flow + decoder repeated
+    syn.debug_set("launch_ahead", 2)
+    syn.run_batch(ids, sid, ls)
+    assert syn.profile()["launch_ahead"] == 0
+    ls2 = [v * 1.25 for v in ls]
+    fresh.run_batch(ids, sid, ls2)
+    want2 = fresh.pcm_host().copy()
+    syn.run_batch(ids, sid, ls2)
+    assert syn.profile()["launch_ahead_misses"] >= 1 and np.array_equal(syn.pcm_host(), want2), "the repeated batch differs from a waiting run"
+    fresh.close()
+    syn.close()
+
+
 def test_multi_device_rccl_gather_with_a_one_rank_communicator():
     """The native RCCL path of sts_multi (ncclCommInitAll, counts by ncclAllGather, gather buffer on device 0, ONE download) on what a
     one-GPU box allows with the REAL librccl: a single-rank communicator.  Same PCM as the per-device download, as a plain engine and
