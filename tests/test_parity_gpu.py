@@ -921,6 +921,43 @@ def test_block_attention_kernel_matches_oracle_at_every_size(kind):
     syn.close()
 
 
+@pytest.mark.parametrize("H,k,half", [(32, 5, 16), (96, 5, 32), (128, 5, 64), (160, 3, 48), (192, 3, 96), (256, 3, 64), (64, 1, 32)])
+def test_flow_layer_kernel_at_every_width_it_admits(H, k, half):
+    """flow_layer_kernel (wn_flow.hip: one launch per WaveNet layer) was tested at H = 64 and 192 only, while
+    flow_layer_shape_ok admits H = 32 ... 256 (with the gate conv's taps limited by the registers a wave keeps its weights in).  Small models
+    with every admitted width / tap count / half-channel count, one utterance and a ragged batch, the latent z and the PCM against the
+    oracle -- and against the per-conv launches, which must not be bit-identical (different arithmetic: that is the evidence the fused
+    kernel engaged)."""
+    import dataclasses
+    cfg = dataclasses.replace(sb.tiny_cfg("hifigan_sdp"), flow_hidden=H, flow_k=k, inter=2 * half, flow_layers=3)
+    blob = sb.make_blob(cfg, 23)
+    port = pyref.PortModel(blob)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    for T in (7, 40):
+        ids = sb.synthetic_ids(T, cfg.vocab, salt=T)
+        o = port.infer_ids(ids, 0, 1.0, taps=True)
+        z = {}
+        for fused in (1, 0):
+            syn.debug_set("flow_fused", fused)
+            syn.run_batch([ids])
+            assert (syn.durations(T) == o["durations"]).all()
+            z[fused] = syn.tap("z").copy()
+            assert np.abs(z[fused] - o["z"]).max() <= TAP_MAXABS_TOL * max(1.0, float(np.abs(o["z"]).max())), (H, k, half, T, fused)
+            assert_pcm_close(syn.pcm_host(), o["pcm"], f"H={H} k={k} half={half} T={T} fused={fused}")
+        assert not np.array_equal(z[1], z[0]), "the one-launch-per-layer kernel did not engage at this width"
+    syn.debug_set("flow_fused", 1)
+    idsb = [sb.synthetic_ids(t, cfg.vocab, salt=t) for t in (11, 5, 19)]
+    n = syn.run_batch(idsb)
+    pcm = syn.pcm_host()
+    off = 0
+    for i, a in enumerate(idsb):
+        o = port.infer_ids(a, 0, 1.0)
+        assert_pcm_close(pcm[off:off + int(n[i])], o["pcm"], f"H={H} batch member {i}")
+        off += int(n[i])
+    syn.close()
+
+
 @pytest.mark.parametrize("kind,size", [("ms_hifigan_sdp", "tiny"), ("mbb_fix", "tiny"), ("hifigan_sdp", "full")])
 def test_launch_ahead_for_packed_batches(kind, size):
     """SURVEY 8 f3, finished in round 5: a packed batch whose members the engine has ALL served before (per-utterance memo: ids, speaker, length
