@@ -164,7 +164,6 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
         case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
         case STS_DBG_PCM_DIRECT: e->eng.pcm_direct = value != 0; return STS_OK;
-        case STS_DBG_UP_WIDE: if (value < 0 || value > 2) return set_err(STS_EINVAL, "up_wide must be 0, 1 or 2"); e->eng.up_wide = value; return STS_OK;
         default: return set_err(STS_EINVAL, "unknown debug key");
     }
 }

@@ -159,28 +159,10 @@ bool conv_bf3_takes_sum(const ConvArgs& a) {
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
     const int nphase = a.transposed ? a.out_stride : 1;
     if (a.max_n <= 0 || a.B <= 0) return;
-    // tile 100 + w (round 5, the engine's up_wide switch): the automatic tile, but a polyphase upsampler stages w-times-wider channel chunks
-    // per barrier.  An upsampling phase has only k / stride taps (2 for every stage of HiFi-GAN), i.e. 24 MFMAs per wave between two
-    // staged chunks: the launch is a chain of staging round trips, and a wider chunk makes the chain shorter (see the tile table below)
-    int wide = 0;
-    if (tile >= 100) { wide = tile - 100; tile = -1; }
     if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
     if (a.nsum >= 2 && tile != 22 && tile != 23) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
-    if (wide > 0 && a.transposed && a.math == 1) {
-        if (tile == 20 && a.Cin_pad % 64 == 0) tile = 25;
-        else if (tile == 0 && wide >= 2 && a.Cin_pad % 64 == 0) tile = 27;
-        else if (tile == 0 && a.Cin_pad % 32 == 0) tile = 26;
-        else if (tile == 22 && a.Cin_pad % 32 == 0) tile = 28;
-        else if (tile == 23 && a.Cin_pad % 32 == 0) tile = 29;
-    }
     switch (tile) {
-        // 25-29: tiles 20 / 0 / 0 / 22 / 23 with 64- / 32- / 64- / 32- / 32-channel staged chunks (two-term fp16 arithmetic only: selected above)
-        case 25: launch_bf3<2, 2, 2, 2, 4, 2, true>(a, nphase, st); break;
-        case 26: launch_bf3<2, 2, 2, 2, 2, 1, true>(a, nphase, st); break;
-        case 27: launch_bf3<2, 2, 2, 2, 4, 1, true>(a, nphase, st); break;
-        case 28: launch_bf3<2, 2, 2, 2, 2, 1, true, true>(a, nphase, st, 1); break;
-        case 29: launch_bf3<1, 2, 2, 2, 2, 1, true, true>(a, nphase, st, 1); break;
         case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         // phase-merged rows (transposed convs): 22: 128 x 128   23: 64 x 128 as two 32-row waves x 2   (lab: 21: 256 x 128, 8 waves)
         case 22: launch_bf3<2, 2, 2, 2, 1, 1, true, true>(a, nphase, st, 1); break;

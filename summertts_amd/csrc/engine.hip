@@ -178,7 +178,7 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     if (use_bf3) {
         if (in_mfma_region_) { mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_++; }
         static const int bt = exp_int("STS_BF3_TILE", -1);   // experiment knob
-        conv_bf3(a, cur_, bt >= 0 ? bt : (a.transposed && up_wide > 0 ? 100 + up_wide : -1));
+        conv_bf3(a, cur_, bt);
     } else if (can_mfma) {
         if (in_mfma_region_) { mfma_flops_ += fl; mfma_exec_ += fl; mfma_launches_++; }
         conv_mfma(a, cur_, o.tile >= 0 ? o.tile : (conv_mode >= 2 ? conv_mode - 2 : -1));

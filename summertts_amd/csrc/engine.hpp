@@ -95,7 +95,6 @@ public:
     // noise scale is 0); the last kMemoEntries distinct utterances, FIFO
     static constexpr size_t kMemoEntries = 1024;
     std::unordered_map<unsigned long long, long> seen_tf_; std::deque<unsigned long long> seen_order_;
-    int up_wide = 0;                   // > 0: the polyphase upsamplers stage 32- (1) / up to 64-channel (2) chunks per barrier (conv_bf3.hip tiles 25-29; sts_debug_set STS_DBG_UP_WIDE)
     int flow_fused = 1;                // 1: the reverse flow as one launch per WaveNet layer where eligible (wn_flow.hip; two-term fp16 arithmetic only);
                                        // 0: one launch per conv (sts_debug_set STS_DBG_FLOW_FUSED)
     hipStream_t stream = nullptr;

@@ -921,40 +921,7 @@ def test_block_attention_kernel_matches_oracle_at_every_size(kind):
     syn.close()
 
 
-@pytest.mark.parametrize("wide", [1, 2])
-@pytest.mark.parametrize("name", ["full_hifigan_sdp_T128.npz", "full_mbb_fix_T96.npz", "real_istft_fix_T96.npz", "full_batch8_hifigan_sdp.npz"])
-def test_wide_chunk_upsampler_tiles_match_reference_golden(name, wide):
-    """Round 5: the polyphase upsamplers with 32- / 64-channel staged chunks per barrier (conv_bf3.hip tiles 25-29, the engine's up_wide
-    switch) -- every upsampler shape of the full-size models (stride 8 / k 16 from 512 and 256 channels, stride 2 / k 4 phase-merged with
-    the chain mean formed while staging, stride 4 / k 16 of the iSTFT families; one utterance and a ragged batch) against the compiled
-    reference's outputs, same tolerances; and bit-identical to the default tiles' PCM is NOT demanded (the K order inside a chunk differs)."""
-    path = [p for p in golden_files_v2("full_") + golden_files_v2("real_") if p.endswith(name)][0]
-    g, cfg, blob, utts, stride = load_golden_v2(path)
-    syn = engine.Synthesizer(blob)
-    syn.set_record_taps(True)
-    syn.debug_set("up_wide", wide)
-    if "batch_lens" in g:
-        lens = [int(t) for t in g["batch_lens"]]
-        ids = [sb.synthetic_ids(t, cfg.vocab, salt=u) for u, t in enumerate(lens)]
-        sid = [int(s) for s in g["batch_sids"]]
-        n = syn.run_batch(ids, sid, [1.0] * len(ids))
-        pcm, wave = syn.pcm_host(), syn.tap("wave")[0]
-        offs = np.concatenate([[0], np.cumsum(n)])
-        for u, ids_u, sid_u, ls_u, dur_u, pcm_u, wave_u in utts:
-            assert np.array_equal(ids_u, ids[u])
-            assert_pcm_close(pcm[offs[u]:offs[u + 1]], pcm_u, f"{name} member {u} wide={wide}")
-            assert_wave_close(wave[offs[u]:offs[u + 1]][::stride], wave_u, f"{name} member {u} wide={wide}")
-    else:
-        for u, ids_u, sid_u, ls_u, dur_u, pcm_u, wave_u in utts:
-            syn.run_batch([ids_u], [sid_u], [ls_u])
-            assert (syn.durations(len(ids_u)) == dur_u).all()
-            assert_pcm_close(syn.pcm_host(), pcm_u, f"{name} wide={wide}")
-            assert_wave_close(syn.tap("wave")[0][::stride], wave_u, f"{name} wide={wide}")
-    assert syn.profile()["conv_math_fallbacks"] == 0
-    syn.close()
-
-
-@pytest.mark.parametrize("H,k,half", [(32, 5, 16), (96, 5, 32), (128, 5, 64), (160, 3, 48), (192, 3, 96), (256, 3, 64), (64, 1, 32)])
+@pytest.mark.parametrize("H,k,half", [(32, 5, 32), (96, 5, 32), (128, 5, 64), (160, 3, 48), (192, 3, 96), (256, 3, 64), (64, 1, 32)])
 def test_flow_layer_kernel_at_every_width_it_admits(H, k, half):
     """flow_layer_kernel (wn_flow.hip: one launch per WaveNet layer) was tested at H = 64 and 192 only, while
     flow_layer_shape_ok admits H = 32 ... 256 (with the gate conv's taps limited by the registers a wave keeps its weights in).  Small models
