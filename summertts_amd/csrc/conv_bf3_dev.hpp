@@ -83,8 +83,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef STS_GROUP_RPF
 #define STS_GROUP_RPF 0
 #endif
-#ifndef STS_KG_AR
-#define STS_KG_AR 2       // weight-fragment ring of the K-group tiles under the two-term arithmetic (see conv_bf3_body)
+#ifndef STS_MW1_WAVES
+#define STS_MW1_WAVES 2
 #endif
 #ifndef STS_H2_MINW
 #define STS_H2_MINW 1
@@ -397,33 +397,22 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 
     // ---- main loop over this wave's steps (chunk, sub-chunk, tap): A (L2) and B (LDS) fragments one step ahead
     // A ring: 2 = the fragments of step s + 1 are requested during step s; 3 (STS_VAR & 16, plain tiles only) = two steps ahead
-    // (round 5) K-group tiles (KG > 1: ONE 8-wave workgroup per CU -- the 256-channel stage and the first upsampler of one utterance) under the
-    // two-term arithmetic: STS_KG_AR.  Their two waves per SIMD belong to the same workgroup and meet at every chunk barrier, so nothing hides
-    // a weight fragment's trip to L2; the tile trace (profiles/r04_tile_trace.log) reads 0.6 us per step against 0.36 us of matrix time
-    constexpr int AR = (NSUB == 1 && KG == 1) ? (MATH == 1 ? STS_H2_AR : ((STS_VAR & 16) ? 3 : 2)) : ((KG > 1 && MATH == 1) ? STS_KG_AR : 2);
-    constexpr bool PLAIN_STEPS = (STS_VAR & (4 | 16 | 32)) != 0 && NSUB == 1 && KG == 1;     // the step index IS the position in the packed weights
+    constexpr int AR = (NSUB == 1 && KG == 1) ? (MATH == 1 ? STS_H2_AR : ((STS_VAR & 16) ? 3 : 2)) : 2;
     u32x4 fa[AR][MW][NPA], fb[2][NW][NPB];
     int sj = 0, ssub = kg, sc = 0;
     auto a_index = [&](int c, int sub, int j) { return (c * NSUB + sub) * a.ntap + j; };
-    // the step whose weight fragments are requested next (tiles with sub-chunks / wave groups): AR - 1 steps ahead of the one being computed
-    int pj = 0, psub = kg, pc = 0;
-    auto a_cursor_next = [&]() {
-        const int idx = a_index(pc, psub, pj);
-        if (++pj == a.ntap) { pj = 0; psub += KG; if (psub >= NSUB) { psub = kg; pc++; } }
-        return idx;
-    };
     auto do_step = [&](u32x4 (&acur)[MW][NPA], u32x4 (&anew)[MW][NPA], u32x4 (&bcur)[NW][NPB], u32x4 (&bnxt)[NW][NPB], int s) {
         int nj = sj + 1, nsub = ssub, nc = sc;
         const bool late_a = (STS_VAR & 32) != 0;       // request the next step's weight fragments in the same block as the MFMAs
         int a_next;
-        if (PLAIN_STEPS) {
+        if ((STS_VAR & (4 | 16 | 32)) && NSUB == 1 && KG == 1) {
             // one sub-chunk, one wave group: the step index IS the position in the packed weights, only (tap, chunk) are tracked
             if (nj == a.ntap) { nj = 0; nc = sc + 1; }
             nsub = 0;
             a_next = s + AR - 1;
         } else {
             if (nj == a.ntap) { nj = 0; nsub = ssub + KG; if (nsub >= NSUB) { nsub = kg; nc = sc + 1; } }
-            a_next = a_cursor_next();       // (AR == 2: the next step's; past the last step the index lies beyond the descriptor or in the next phase's block: read, never used)
+            a_next = a_index(nc, nsub, nj);
         }
         if (!late_a && (!(STS_EXP & 2) || s < 2)) load_a(a_next, anew);   // unconditional: past the last step it reads 0 beyond the descriptor, never used
         if (nc != sc && s + 1 < nsteps) {
@@ -454,13 +443,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         if (rpf) tile_res_prefetch<MW, NW, NTL>(a, rpre, mbase, n0 + wn * NW * 32, l31, half, n_count, out_len, out_base, phase);
     }
     load_x(0);
-    if constexpr (PLAIN_STEPS) {
-        load_a(0, fa[0]);
-        if constexpr (AR >= 3) load_a(1, fa[1]);
-        if constexpr (AR >= 4) load_a(2, fa[2]);
-    } else {
-        static_for<0, AR - 1>([&](auto rc) { load_a(a_cursor_next(), fa[decltype(rc)::value]); });
-    }
+    load_a(a_index(0, kg, 0), fa[0]);
+    if constexpr (AR >= 3) load_a(1, fa[1]);
+    if constexpr (AR >= 4) load_a(2, fa[2]);
     store_tile(0);
     __syncthreads();
     TT_STAMP(1);
@@ -540,8 +525,10 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 #endif
 }
 
+// (STS_MW1_WAVES: the 32-rows-per-wave tiles need < 168 registers by themselves; capping them there lets a THIRD workgroup share the CU -- the last
+// upsampler of one utterance is 669 workgroups on 512 slots: one full round and a 30 % one, profiles/r04_tile_trace.log launch 34)
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, int MATH = 0, bool NSUM = false>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(MATH ? STS_H2_MINW : 1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(MATH ? STS_H2_MINW : 1, MATH ? (MW == 1 && KG == 1 ? STS_MW1_WAVES : STS_H2_WAVES) : 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
     const TileId t = map_tile(nx, ny, a.B);
     if (!t.valid) return;
     conv_bf3_body<MW, NW, WM, WN, NSUB, KG, false, MATH, NSUM>(a, mtiles, t.bx, t.by, t.bz, pm);
