@@ -83,8 +83,20 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef STS_GROUP_RPF
 #define STS_GROUP_RPF 0
 #endif
+// Occupancy of the staged two-term kernels (round 5, profiles/r05_ab_log.md session 5).  STS_MW1_WAVES: the single-conv tiles whose waves own 32 rows need 124-148
+// registers by themselves; allowing a THIRD workgroup per CU turns the last upsampler of one utterance (669 workgroups on 512 slots: a full round and a
+// 30 % one, profiles/r04_tile_trace.log launch 34) into one round: 35.1 -> 25.6 us.  STS_GROUP_MINW / _WAVES: the plain 128 x 128 tile of the GROUPED launches
+// (the 128-channel ResBlock stage) capped at 168 registers = three workgroups per CU (a 20-byte spill): 104.0 -> 99.4 us per launch at one utterance,
+// MB-iSTFT batch 64 -3.2 % of the step.  The same cap on every staged kernel is a wash: the phase-merged upsampler tile that forms the chain mean while
+// staging (198 registers) spills and doubles (34 -> 64 us), which is why the switches are per kernel family.
 #ifndef STS_MW1_WAVES
-#define STS_MW1_WAVES 2
+#define STS_MW1_WAVES 3
+#endif
+#ifndef STS_GROUP_MINW
+#define STS_GROUP_MINW 3
+#endif
+#ifndef STS_GROUP_WAVES
+#define STS_GROUP_WAVES 3
 #endif
 #ifndef STS_H2_MINW
 #define STS_H2_MINW 1
@@ -525,8 +537,6 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
 #endif
 }
 
-// (STS_MW1_WAVES: the 32-rows-per-wave tiles need < 168 registers by themselves; capping them there lets a THIRD workgroup share the CU -- the last
-// upsampler of one utterance is 669 workgroups on 512 slots: one full round and a 30 % one, profiles/r04_tile_trace.log launch 34)
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, int MATH = 0, bool NSUM = false>
 __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(MATH ? STS_H2_MINW : 1, MATH ? (MW == 1 && KG == 1 ? STS_MW1_WAVES : STS_H2_WAVES) : 2))) void conv_bf3_kernel(ConvArgs a, int mtiles, int nx, int ny, int pm) {
     const TileId t = map_tile(nx, ny, a.B);
@@ -536,7 +546,8 @@ __global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_e
 
 // grouped launch (layer d of all ResBlock chains of a stage in one grid), see conv_mfma_group_kernel
 template <int MW, int NW, int WM, int WN, int NSUB, int KG = 1, int MATH = 0>
-__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(MATH ? STS_H2_MINW : 1, MATH ? STS_H2_WAVES : 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny, int interleave) {
+__global__ __launch_bounds__(WM* WN * KG * 64) __attribute__((amdgpu_waves_per_eu(MATH ? (KG == 1 && MW == 2 && WM == 2 ? STS_GROUP_MINW : STS_H2_MINW) : 1,
+                                                                                     MATH ? (KG == 1 && MW == 2 && WM == 2 ? STS_GROUP_WAVES : STS_H2_WAVES) : 2))) void conv_bf3_group_kernel(ConvGroup G, int mtiles, int B, int nx, int ny, int interleave) {
     const TileId t = map_tile(nx, ny, B * G.n);
     if (!t.valid) return;
     // interleave: consecutive dispatch units belong to different members (different K lengths), so that workgroups that
