@@ -1413,29 +1413,34 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
         const int j = i / a.Cin, ci = i - j * a.Cin;
         ws[i] = a.w[((size_t)j * a.Cin_pad + ci) * a.Cout_pad];
     }
-    // window staging: 8 rows per round, all of a round's loads issued before any is used (the kernel is pure HBM streaming:
-    // one dependent load per row made it latency-bound at ~0.8 TB/s)
+    // window staging: CB rows per round, all of a round's loads issued before any is used (the kernel is pure HBM streaming: one dependent
+    // load per row made it latency-bound at ~0.8 TB/s; 8 rows per round -- 24 loads in flight with the three-tensor mean -- reached ~2 TB/s;
+    // round 5: 16 rows per round)
+#ifndef STS_COUT1_CB
+#define STS_COUT1_CB 16
+#endif
+    constexpr int CB = STS_COUT1_CB;
     for (int col = threadIdx.x; col < W; col += 256) {
         const int pos = n0 + a.tap_off + col;
         const bool ok = pos >= 0 && pos < in_len;
         const size_t coff = in_base + (ok ? pos : 0);
         const float* xcol = a.x + coff;
-        for (int c0 = 0; c0 < a.Cin; c0 += 8) {
-            float v[8];
+        for (int c0 = 0; c0 < a.Cin; c0 += CB) {
+            float v[CB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = (ok && c0 + u < a.Cin) ? xcol[(size_t)(c0 + u) * a.x_ld] : 0.f;
+            for (int u = 0; u < CB; u++) v[u] = (ok && c0 + u < a.Cin) ? xcol[(size_t)(c0 + u) * a.x_ld] : 0.f;
             if (a.nsum >= 2) {      // the input is the mean of 2 / 3 tensors (ConvArgs::nsum), formed in sum_scale's order
-                float v1[8], v2[8];
+                float v1[CB], v2[CB];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v1[u] = (ok && c0 + u < a.Cin) ? a.xs1[coff + (size_t)(c0 + u) * a.x_ld] : 0.f;
+                for (int u = 0; u < CB; u++) v1[u] = (ok && c0 + u < a.Cin) ? a.xs1[coff + (size_t)(c0 + u) * a.x_ld] : 0.f;
 #pragma unroll
-                for (int u = 0; u < 8; u++) v2[u] = (a.nsum > 2 && ok && c0 + u < a.Cin) ? a.xs2[coff + (size_t)(c0 + u) * a.x_ld] : 0.f;
+                for (int u = 0; u < CB; u++) v2[u] = (a.nsum > 2 && ok && c0 + u < a.Cin) ? a.xs2[coff + (size_t)(c0 + u) * a.x_ld] : 0.f;
                 const float div = (float)a.nsum;
 #pragma unroll
-                for (int u = 0; u < 8; u++) { float t = v[u] + v1[u]; if (a.nsum > 2) t += v2[u]; v[u] = t / div; }
+                for (int u = 0; u < CB; u++) { float t = v[u] + v1[u]; if (a.nsum > 2) t += v2[u]; v[u] = t / div; }
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < CB; u++)
                 if (c0 + u < a.Cin) {
                     float t = v[u];
                     if (a.in_act) t = t < 0.f ? t * a.in_slope : t;
