@@ -1414,10 +1414,10 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
         ws[i] = a.w[((size_t)j * a.Cin_pad + ci) * a.Cout_pad];
     }
     // window staging: CB rows per round, all of a round's loads issued before any is used (the kernel is pure HBM streaming: one dependent
-    // load per row made it latency-bound at ~0.8 TB/s; 8 rows per round -- 24 loads in flight with the three-tensor mean -- reached ~2 TB/s;
-    // round 5: 16 rows per round)
+    // load per row made it latency-bound at ~0.8 TB/s; 8 rows per round -- 24 loads in flight with the three-tensor mean -- reached ~2 TB/s).
+    // Round 5 measured 16 and 32 rows per round on one box (profiles/r05_ab_log.md): 33.2 us (8) / 36.6 (16) / 32.3 (32) -- nothing to gain
 #ifndef STS_COUT1_CB
-#define STS_COUT1_CB 16
+#define STS_COUT1_CB 8
 #endif
     constexpr int CB = STS_COUT1_CB;
     for (int col = threadIdx.x; col < W; col += 256) {
