@@ -114,8 +114,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 16
 // take a branch-free path: a row tile's 16 bias values and a column tile's 16 residual values are requested together
 // and waited for once.  (Measured: with the per-element epilogue switch each of a lane's 64 outputs paid its own dependent
 // bias load -- ~31 us of a 57 us tile for a 3-tap 128-channel conv.)
-// NTL: the residual is read with non-temporal loads (persistent stage kernel: it was written by another CU of this XCD inside
-// the same launch, a plain load could hit a stale line of this CU's vector L1)
+// NTL: the residual is read with non-temporal loads (for data written by another CU of this XCD inside the same launch: a plain load could
+// hit a stale line of this CU's vector L1).  Always false since the persistent stage kernel of round 3 was deleted (round 5)
 // The residual operand of the plain / residual epilogue below (EPI_RESADD, unit output stride), requested AHEAD of the K loop: the tile's
 // 16-byte residual loads then land under the MFMAs instead of costing the epilogue a memory round trip (round 4, tile trace: epilogue of a
 // 128 x 128 tile 7.5 us without a residual, 11.5 us with one).  Same addresses, same predicates as the epilogue's own loads.

@@ -63,8 +63,8 @@ struct ConvArgs {
     // optional split-bf16 form of the same weights (conv_bf3.hip): every fp32 weight as three bf16 terms, fragment-packed by
     // bf3_pack(); null = this conv only has the fp32 matrix-core path
     const void* wb3;
-    // optional restriction of the OUTPUT to the columns n in [keep_lo, keep_hi) (keep_hi == 0: all): a window of the persistent
-    // stage kernel computes its halo columns but must not publish them (plain / residual epilogue of non-polyphase convs only)
+    // optional restriction of the OUTPUT to the columns n in [keep_lo, keep_hi) (keep_hi == 0: all; plain / residual epilogue of
+    // non-polyphase convs only).  No caller sets it since the persistent stage kernel of round 3 was deleted (round 5); the epilogues keep the test
     int keep_lo, keep_hi;
     // arithmetic of the wb3 copy (conv_bf3.hip): 0 = three bf16 terms / six products, 1 = two fp16 terms / three products with the
     // weights scaled by a power of two (wscale = its inverse, applied to the finished tile); ovf (math 1): raised when a staged
