@@ -748,12 +748,15 @@ def main():
             pool = eng.Pool(blob, device=0, n_engines=args.pipeline_engines, max_batch=mb)
             for t_ in [pool.submit(ids[0], sid[0], ls[0]) for _ in range(2 * args.pipeline_engines)]:
                 pool.wait(t_)                                    # warm-up: every engine has run once
-            tp0 = time.perf_counter()
-            tk = [pool.submit(ids[u % len(ids)], sid[u % len(ids)], ls[u % len(ids)]) for u in range(nreq)]
-            done = sum(int(pool.wait(t_).size) for t_ in tk)
-            tp = time.perf_counter() - tp0
+            rounds = []                                          # three rounds of nreq requests: the median one is reported (one round of
+            for _ in range(3):                                   # 20 requests is 40 ms: a single host hiccup used to decide the figure)
+                tp0 = time.perf_counter()
+                tk = [pool.submit(ids[u % len(ids)], sid[u % len(ids)], ls[u % len(ids)]) for u in range(nreq)]
+                done = sum(int(pool.wait(t_).size) for t_ in tk)
+                rounds.append((time.perf_counter() - tp0, done))
+            tp, done = sorted(rounds)[1]
             pipelined[label] = {"value": done / tp, "unit": "samples/s", "x_realtime_16khz": done / tp / 16000.0,
-                                "ms_per_request": 1e3 * tp / nreq}
+                                "ms_per_request": 1e3 * tp / nreq, "ms_per_request_rounds": [round(1e3 * r_[0] / nreq, 3) for r_ in rounds]}
             pool.close()
 
     total_samples = samples
