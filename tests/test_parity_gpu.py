@@ -162,10 +162,13 @@ def test_f16x2_conv_against_float64(case):
     assert np.array_equal(y, y1)
 
 
-def test_f16x2_falls_back_when_an_activation_leaves_the_fp16_range():
+@pytest.mark.parametrize("stats", ["gaussian", "realistic"])
+def test_f16x2_falls_back_when_an_activation_leaves_the_fp16_range(stats):
     """A model whose decoder activations exceed 65504 (conv_pre weights scaled up) trips the overflow word of the two-term fp16
-    kernels; the engine repeats the call in the split-bf16 form, counts it, and returns exactly the split-bf16 result."""
-    cfg = sb.full_cfg("hifigan_sdp")
+    kernels; the engine repeats the call in the split-bf16 form, counts it, and returns exactly the split-bf16 result.  (Round 5: also on
+    the checkpoint-like weight statistics -- per-channel gains, outliers, biases --, where the range logic had never been driven to its limit.)"""
+    import dataclasses
+    cfg = dataclasses.replace(sb.full_cfg("hifigan_sdp"), stats=stats)
     blob = sb.make_blob(cfg, 5)
     ids = sb.synthetic_ids(20, cfg.vocab)
     syn = engine.Synthesizer(blob)
@@ -176,7 +179,7 @@ def test_f16x2_falls_back_when_an_activation_leaves_the_fp16_range():
     assert syn.profile()["conv_math_fallbacks"] == 0
     syn.close()
     # the decoder's input conv is the first conv after the text encoder and the generator header in the blob (synth_blob.make_blob)
-    w = sb._W(5)
+    w = sb._W(5, stats)
     w.ints(cfg.is_ms, cfg.lang, cfg.dur_type, cfg.dec_type)
     sb._text_encoder(w, cfg)
     sb._gen_hdr(w, cfg)

@@ -80,6 +80,10 @@ CASES = {
     "real_tiny_ms_sdp": dict(kind="ms_sdp", size="tiny", overrides=dict(stats="realistic"), utts=[(20, 1, 0, 1.0)], z_stride=1),
     "real_tiny_istft_fix": dict(kind="istft_fix", size="tiny", overrides=dict(stats="realistic"), utts=[(20, 1, 0, 0.9)], z_stride=1),
     "real_tiny_ms_hifigan_fix": dict(kind="ms_hifigan_fix", size="tiny", overrides=dict(stats="realistic"), utts=[(20, 1, 2, 1.0)], z_stride=1),
+    # ragged 8-utterance batches on the realistic statistics: at batch the flow / text-encoder convs run in the two-term fp16 form too (from ~384
+    # workgroups per launch on), which no single-utterance fixture reaches
+    "full_real_batch8_hifigan_sdp": dict(batch_case("hifigan_sdp", 2), overrides=dict(stats="realistic", dur_bias=0.6, post_gain=2.5)),
+    "full_real_batch8_mbb_fix": dict(batch_case("mbb_fix", 2), overrides=dict(stats="realistic", mag_bias=1.1)),
     # the first full-size Generator_Istft fixture on the Gaussian recipe (VERDICT r04 missing item 5)
     "full_istft_fix_T96": dict(kind="istft_fix", size="full", utts=[(96, 3, 0, 1.0)]),
 }
