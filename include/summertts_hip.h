@@ -133,7 +133,6 @@ int sts_set_conv_math(sts_engine* e, int mode);
  *   (Keys 2-4 selected the two persistent-kernel families of round 3; both lost their A/B against the launch path and were deleted
  *   in round 5 -- the numbers stay retired and answer STS_EINVAL.) */
 enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1,
-       STS_DBG_CHAIN_SPLIT = 10 /* decoder ResBlock stages: bit 0 set + bit (1 + stage) set = that stage's chains go out as two launch sequences on two streams (the heaviest chain | the others) instead of one grouped launch per layer; 0 = grouped launches */,
        STS_DBG_PCM_DIRECT = 9 /* sts_set_host_pcm(1), one utterance: 1 (default) the decoder's last kernel writes the PCM into the pinned host buffer itself, 0 a download behind it */,
        STS_DBG_DDS_TAIL = 8 /* stochastic duration predictor: 1 (default) a ConvFlow's projection + spline step ride in its last DDSConv layer's launch, 0 three launches */,
        STS_DBG_ATTN_REG = 7 /* one-query attention: 1 (default) operands in registers (attention_reg_kernel), 0 the round-1 kernel */,

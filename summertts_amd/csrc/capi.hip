@@ -164,7 +164,6 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
         case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
         case STS_DBG_PCM_DIRECT: e->eng.pcm_direct = value != 0; return STS_OK;
-        case STS_DBG_CHAIN_SPLIT: if (value < 0 || value > 0x1fff) return set_err(STS_EINVAL, "chain_split is a mask (bit 0 = on, bits 1-4 = stages on two streams, bits 5-8 = stages on three)"); e->eng.chain_split = value; return STS_OK;
         default: return set_err(STS_EINVAL, "unknown debug key");
     }
 }

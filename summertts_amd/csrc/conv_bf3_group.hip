@@ -41,14 +41,6 @@ bool conv_bf3_group_eligible(const ConvGroup& G) {
     return true;
 }
 
-// the tile code the automatic choice gives this group (callers that launch the members of one layer as several sub-groups pass it on, so
-// that the sub-launches use the tile of the whole layer)
-int conv_bf3_group_tile(const ConvGroup& G) {
-    if (G.n < 1) return -1;
-    const ConvArgs& a = G.g[0];
-    return pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * G.n, false, a.math);
-}
-
 void conv_bf3_group(const ConvGroup& Gin, hipStream_t st, int tile) {
     ConvGroup G = Gin;
     if (G.g[0].max_n <= 0 || G.g[0].B <= 0) return;

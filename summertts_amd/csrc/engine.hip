@@ -1043,17 +1043,6 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                 (void)hipEventRecord(ev_fork_, stream);
                 for (int k = 0; k < kAux; k++) (void)hipStreamWaitEvent(aux_[k], ev_fork_, 0);
             }
-            // chain_split (round 5): the heaviest chain's launches stay on the engine's stream, the other chains' go out as a second sequence of
-            // grouped launches on an auxiliary stream -- two dependent launch sequences of about equal work (k = 11 against k = 7 + 3) whose
-            // ramp-up and tail phases (profiles/r05_tile_trace.log: slot fill 0.72-0.82 per launch) overlap each other's bodies instead of idling the chip
-            int jmax = 0;
-            for (int j = 0; j < nk; j++) if (crank[j] == nk - 1) jmax = j;
-            const bool split3 = chain_split != 0 && ((chain_split >> (5 + i)) & 1) && !per_chain && nk == 3 && kAux >= 2 && conv_math != 1 && conv_mode == 0;
-            const bool split2 = split3 || (chain_split != 0 && ((chain_split >> (1 + i)) & 1) && !per_chain && nk >= 2 && conv_math != 1 && conv_mode == 0);
-            hipStream_t sB = aux_[kAux - 1], sC = aux_[kAux - 2];          // (the highest-priority auxiliary streams)
-            int jmid = -1;                                                  // split3: the middle chain gets a stream of its own too
-            for (int j = 0; j < nk && split3; j++) if (crank[j] == 1) jmid = j;
-            if (split2) { (void)hipEventRecord(ev_fork_, stream); (void)hipStreamWaitEvent(sB, ev_fork_, 0); if (split3) (void)hipStreamWaitEvent(sC, ev_fork_, 0); }
             static const bool no_fuse = exp_flag("STS_NO_FUSE");   // experiment knob
             for (int d = 0; d < nd0; d++) {
                 // narrow stages: the whole layer (conv1 -> lrelu -> conv2 -> + x) of all chains in one launch
@@ -1106,15 +1095,6 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                     const bool wino = !no_wino && resblock_wino_eligible(R);
                     if (bf3_layer && resblock_bf3_eligible(R)) {
                         static const int bv = exp_int("STS_BF3_LAYER_VARIANT", -1);   // experiment knob
-                        if (split2) {
-                            ResLayerGroup RA = R, RB = R;
-                            RA.n = 1; RA.g[0] = R.g[jmax];
-                            RB.n = 0;
-                            for (int j = 0; j < nk; j++) if (j != jmax && j != jmid) RB.g[RB.n++] = R.g[j];
-                            resblock_bf3(RA, stream, bv);
-                            if (jmid >= 0) { ResLayerGroup RC = R; RC.n = 1; RC.g[0] = R.g[jmid]; resblock_bf3(RC, sC, bv); }
-                            resblock_bf3(RB, sB, bv);
-                        } else
                         resblock_bf3(R, stream, bv);
                         mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_ += 1;
                         continue;
@@ -1157,19 +1137,8 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                 if ((conv_math != 1) && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
                     static const char* bgt = exp_env("STS_BF3_GROUP_TILE");   // experiment knob: per-stage tile digits
                     const int bt = bgt && (int)strlen(bgt) > i ? (bgt[i] >= '0' && bgt[i] <= '9' ? bgt[i] - '0' : (bgt[i] >= 'a' && bgt[i] <= 'z' ? bgt[i] - 'a' + 10 : -1)) : -1;
-                    if (split2) {
-                        ConvGroup A1, B1, A2, B2;
-                        A1.n = A2.n = 1; A1.g[0] = G1.g[jmax]; A2.g[0] = G2.g[jmax];
-                        B1.n = B2.n = 0;
-                        for (int j = 0; j < nk; j++) if (j != jmax && j != jmid) { B1.g[B1.n++] = G1.g[j]; B2.g[B2.n++] = G2.g[j]; }
-                        const int t1 = bt >= 0 ? bt : conv_bf3_group_tile(G1), t2 = bt >= 0 ? bt : conv_bf3_group_tile(G2);     // the tiles of the whole layer
-                        conv_bf3_group(A1, stream, t1); conv_bf3_group(A2, stream, t2);
-                        if (jmid >= 0) { ConvGroup C1, C2; C1.n = C2.n = 1; C1.g[0] = G1.g[jmid]; C2.g[0] = G2.g[jmid]; conv_bf3_group(C1, sC, t1); conv_bf3_group(C2, sC, t2); }
-                        conv_bf3_group(B1, sB, t1); conv_bf3_group(B2, sB, t2);
-                    } else {
                     conv_bf3_group(G1, stream, bt);
                     conv_bf3_group(G2, stream, bt);
-                    }
                     mfma_flops_ += fl1 + fl2; bf16_exec_ += products() * (fl1 + fl2); mfma_launches_ += 2;
                     continue;
                 }
@@ -1181,8 +1150,6 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             }
             if (per_chain)
                 for (int k = 0; k < kAux; k++) { (void)hipEventRecord(ev_join_[k], aux_[k]); (void)hipStreamWaitEvent(stream, ev_join_[k], 0); }
-            if (split2) { (void)hipEventRecord(ev_join_[0], sB); (void)hipStreamWaitEvent(stream, ev_join_[0], 0); }
-            if (split3) { (void)hipEventRecord(ev_join_[1], sC); (void)hipStreamWaitEvent(stream, ev_join_[1], 0); }
             for (int j = 0; j < nk; j++) outs[j] = cur[j];
         } else {
             // fallback: the chains run concurrently on separate HIP streams

@@ -227,7 +227,6 @@ void conv_bf3(const ConvArgs& a, hipStream_t st, int tile = -1);
 long conv_bf3_blocks(const ConvArgs& a);
 bool conv_bf3_group_eligible(const ConvGroup& G);
 void conv_bf3_group(const ConvGroup& G, hipStream_t st, int tile = -1);
-int conv_bf3_group_tile(const ConvGroup& G);
 // wp: packed fp32 weights [nslab][Cin_pad][Cout_pad] (nslab = taps, or phases x taps of a polyphase transposed conv)
 // -> dst: [slab-major, see conv_bf3.hip] 3 x bf16; returns the number of bytes written (dst == null: size query)
 // perm_k: the 16 input channels of a chunk in the order the fused layer kernel parks its intermediate in (k slot (h, e) of a
