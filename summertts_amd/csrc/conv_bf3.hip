@@ -90,10 +90,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
-#ifndef STS_BF3_REFLECT
-#define STS_BF3_REFLECT 1     // (0: lab A/B -- the reflect-padded subband conv of the iSTFT families stays on the exact-fp32 MFMA kernel, as before round 5)
-#endif
-    if (!a.wb3 || a.depthwise || (a.in_reflect && (a.transposed || !STS_BF3_REFLECT))) return false;
+    if (!a.wb3 || a.depthwise || a.in_reflect) return false;
     if (a.Cin != a.Cin_pad || a.Cin_pad % CK != 0 || a.Cout_pad % 32 != 0 || a.Cin < 32) return false;
     if ((double)a.x_ld * 64.0 >= 4.0e9) return false;       // 16 rows of a chunk behind one 32-bit buffer descriptor
     const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
