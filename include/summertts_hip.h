@@ -133,6 +133,9 @@ int sts_set_conv_math(sts_engine* e, int mode);
  *   (Keys 2-4 selected the two persistent-kernel families of round 3; both lost their A/B against the launch path and were deleted
  *   in round 5 -- the numbers stay retired and answer STS_EINVAL.) */
 enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1,
+       STS_DBG_H2P = 11 /* decoder stages of 128 k channels under the two-term fp16 arithmetic: 1 (default) pre-split channel-minor activations (conv_h2p.hip), 0 the staged kernels */,
+       STS_DBG_H2P_TILE = 12 /* lab: tile code of conv_h2p_group, -1 automatic */,
+       STS_DBG_MEMO_CLEAR = 10 /* any value: forget the launch-ahead memo (bench.py: every timed request is then one the engine has not served before) */,
        STS_DBG_PCM_DIRECT = 9 /* sts_set_host_pcm(1), one utterance: 1 (default) the decoder's last kernel writes the PCM into the pinned host buffer itself, 0 a download behind it */,
        STS_DBG_DDS_TAIL = 8 /* stochastic duration predictor: 1 (default) a ConvFlow's projection + spline step ride in its last DDSConv layer's launch, 0 three launches */,
        STS_DBG_ATTN_REG = 7 /* one-query attention: 1 (default) operands in registers (attention_reg_kernel), 0 the round-1 kernel */,
@@ -192,6 +195,14 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
                            int32_t Cout, int32_t k, int32_t pad, int32_t dil, int32_t stride_transposed,
                            int32_t depthwise, float in_slope, int32_t in_act, int mode, float** y, int32_t* Lout,
                            int32_t iters, float* ms_out);
+
+/* One "same"-padded conv (odd k, pad = dil (k - 1) / 2) through the pre-split path of the wide decoder stages (conv_h2p.hip): x fp32
+ * [Cin][L] -> split_planes(in_slope) -> conv_h2p_group with `members` identical members -> member 0's three output forms, each decoded to
+ * fp32 [Cout][L] (null: not wanted): y = the channel-major fp32 output, y16 = the channel-minor fp32 copy, yp = the two fp16 planes of
+ * lrelu(out, out_slope) recombined.  res: optional residual [Cout][L].  tile < 0: automatic. */
+int sts_debug_conv_h2p(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias, int32_t Cout, int32_t k,
+                       int32_t dil, const float* res, float in_slope, float out_slope, int tile, int members, float* y, float* y16,
+                       float* yp, int32_t iters, float* ms_out);
 
 void sts_free(void* p);
 const char* sts_last_error(void);

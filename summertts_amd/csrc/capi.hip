@@ -161,6 +161,9 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_ATTN_BLOCK_MIN_WGS: if (value < 1) return set_err(STS_EINVAL, "threshold must be >= 1"); e->eng.attn_block_min_wgs = value; return STS_OK;
         case STS_DBG_FLOW_FUSED: e->eng.flow_fused = value != 0; return STS_OK;
         case STS_DBG_LAUNCH_AHEAD: if (value < 0 || value > 2) return set_err(STS_EINVAL, "launch_ahead must be 0, 1 or 2"); if ((value == 2) != (e->eng.launch_ahead == 2)) { e->eng.seen_tf_.clear(); e->eng.seen_order_.clear(); } e->eng.launch_ahead = value; return STS_OK;
+        case STS_DBG_H2P: e->eng.h2p = value != 0; return STS_OK;
+        case STS_DBG_H2P_TILE: e->eng.h2p_tile = value; return STS_OK;
+        case STS_DBG_MEMO_CLEAR: e->eng.seen_tf_.clear(); e->eng.seen_order_.clear(); return STS_OK;
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
         case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
         case STS_DBG_PCM_DIRECT: e->eng.pcm_direct = value != 0; return STS_OK;
@@ -332,6 +335,96 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         }
     }
     (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dseg); if (dwu) (void)hipFree(dwu); if (dwb3) (void)hipFree(dwb3);
+    return rc;
+}
+
+// One "same"-padded conv through the pre-split path (conv_h2p.hip): x fp32 [Cin][L] -> split_planes -> conv_h2p_group (`members` identical
+// members in one grid; member 0 is returned) -> all three output forms decoded to fp32 [Cout][L] on the host.
+int sts_debug_conv_h2p(int device, const float* x, int32_t Cin, int32_t L, const float* w, const float* bias, int32_t Cout, int32_t k, int32_t dil,
+                       const float* res, float in_slope, float out_slope, int tile, int members, float* y_out, float* y16_out, float* yp_out,
+                       int32_t iters, float* ms_out) {
+    if (!x || !w || Cin <= 0 || Cout <= 0 || L <= 0 || k <= 0 || !(k & 1) || dil < 1 || members < 1 || members > kMaxGroup) return set_err(STS_EINVAL, "bad conv arguments");
+    if (Cin % 16 || Cout % 32) return set_err(STS_EINVAL, "pre-split conv: Cin % 16 == 0 and Cout % 32 == 0");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return set_err(STS_EDEVICE, "no HIP device visible (no CPU fallback)");
+    if (hipSetDevice(device) != hipSuccess) return set_err(STS_EDEVICE, "hipSetDevice failed");
+    const int pad = dil * (k - 1) / 2;
+    std::vector<float> wp((size_t)k * Cin * Cout, 0.f);
+    for (int o = 0; o < Cout; o++) for (int t = 0; t < k; t++) for (int ci = 0; ci < Cin; ci++)
+        wp[((size_t)t * Cin + ci) * Cout + o] = w[((size_t)o * k + t) * Cin + ci];
+    std::vector<unsigned char> wb(bf3_pack(wp.data(), 1, k, Cin, Cout, nullptr, true, 1));
+    float wscale = 1.0f;
+    bf3_pack(wp.data(), 1, k, Cin, Cout, wb.data(), true, 1, &wscale);
+    const size_t in_b = (size_t)Cin * L * 4, out_b = (size_t)Cout * L * 4;
+    float *dx = nullptr, *db = nullptr, *dres = nullptr, *dres16 = nullptr; void *dxp = nullptr, *dwb = nullptr, *dtmp = nullptr; unsigned* dovf = nullptr;
+    float* dy[kMaxGroup] = {}; float* dy16[kMaxGroup] = {}; void* dyp[kMaxGroup] = {};
+    bool ok = hipMalloc((void**)&dx, in_b) == hipSuccess && hipMalloc(&dxp, in_b) == hipSuccess && hipMalloc(&dwb, wb.size() + 8192) == hipSuccess &&
+              hipMalloc((void**)&db, (size_t)Cout * 4) == hipSuccess && hipMalloc((void**)&dovf, 64) == hipSuccess;
+    if (ok && res) ok = hipMalloc((void**)&dres, out_b) == hipSuccess && hipMalloc((void**)&dres16, out_b) == hipSuccess && hipMalloc(&dtmp, out_b) == hipSuccess;
+    for (int m = 0; m < members && ok; m++)
+        ok = hipMalloc((void**)&dy[m], out_b) == hipSuccess && hipMalloc((void**)&dy16[m], out_b) == hipSuccess && hipMalloc(&dyp[m], out_b) == hipSuccess;
+    int rc = ok ? STS_OK : set_err(STS_EDEVICE, "hipMalloc failed");
+    if (rc == STS_OK) {
+        (void)hipMemcpy(dx, x, in_b, hipMemcpyHostToDevice);
+        (void)hipMemset(dwb, 0, wb.size() + 8192);
+        (void)hipMemcpy(dwb, wb.data(), wb.size(), hipMemcpyHostToDevice);
+        (void)hipMemset(db, 0, (size_t)Cout * 4);
+        if (bias) (void)hipMemcpy(db, bias, (size_t)Cout * 4, hipMemcpyHostToDevice);
+        (void)hipMemset(dovf, 0, 64);
+        split_planes(dx, L, Cin, L, in_slope, dxp, nullptr, L, dovf, nullptr);
+        if (res) {
+            (void)hipMemcpy(dres, res, out_b, hipMemcpyHostToDevice);
+            split_planes(dres, L, Cout, L, 1.0f, dtmp, dres16, L, nullptr, nullptr);
+        }
+        H2PGroup G;
+        memset(&G, 0, sizeof(G));
+        G.n = members; G.seg = SegView{nullptr, nullptr, 1, 0, 0, L}; G.B = 1; G.max_n = L; G.ovf = dovf;
+        for (int m = 0; m < members; m++) {
+            H2PArgs& a = G.g[m];
+            a.xp = dxp; a.xp_ld = L; a.wb = dwb; a.wscale = wscale; a.bias = bias ? db : nullptr; a.res16 = dres16; a.res_ld = L;
+            a.y = dy[m]; a.y_ld = L; a.y16 = dy16[m]; a.y16_ld = L; a.yp = dyp[m]; a.yp_ld = L; a.yp_slope = out_slope;
+            a.Cin = Cin; a.Cout = Cout; a.ntap = k; a.tap_step = dil; a.tap_off = -pad;
+        }
+        if (!conv_h2p_group_eligible(G)) rc = set_err(STS_EINVAL, "shape not eligible for the pre-split kernel");
+        else {
+            conv_h2p_group(G, nullptr, tile);
+            if (iters > 0 && ms_out) {
+                hipEvent_t e0, e1;
+                (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                (void)hipDeviceSynchronize();
+                (void)hipEventRecord(e0, nullptr);
+                for (int it = 0; it < iters; it++) conv_h2p_group(G, nullptr, tile);
+                (void)hipEventRecord(e1, nullptr);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                *ms_out = ms / (float)iters;
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            }
+            if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = set_err(STS_EDEVICE, "conv kernel failed");
+        }
+        if (rc == STS_OK) {
+            if (y_out) (void)hipMemcpy(y_out, dy[0], out_b, hipMemcpyDeviceToHost);
+            std::vector<float> t16((size_t)Cout * L);
+            std::vector<uint16_t> tp((size_t)Cout * L * 2);
+            (void)hipMemcpy(t16.data(), dy16[0], out_b, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(tp.data(), dyp[0], out_b, hipMemcpyDeviceToHost);
+            const size_t ps = (size_t)Cout * L;       // fp16 values per plane
+            for (int c = 0; c < Cout / 16; c++) for (long t = 0; t < L; t++) for (int h = 0; h < 2; h++) for (int e = 0; e < 8; e++) {
+                const int ch = 16 * c + 8 * (e >> 2) + 4 * h + (e & 3);
+                const size_t u = ((size_t)c * L + t) * 16 + h * 8 + e;
+                if (y16_out) y16_out[(size_t)ch * L + t] = t16[u];
+                if (yp_out) {
+                    _Float16 hi, lo;
+                    memcpy(&hi, &tp[u], 2); memcpy(&lo, &tp[ps + u], 2);
+                    yp_out[(size_t)ch * L + t] = (float)hi + (float)lo * (1.0f / 2048.0f);
+                }
+            }
+        }
+    }
+    (void)hipFree(dx); (void)hipFree(dxp); (void)hipFree(dwb); (void)hipFree(db); (void)hipFree(dovf);
+    if (dres) (void)hipFree(dres); if (dres16) (void)hipFree(dres16); if (dtmp) (void)hipFree(dtmp);
+    for (int m = 0; m < kMaxGroup; m++) { if (dy[m]) (void)hipFree(dy[m]); if (dy16[m]) (void)hipFree(dy16[m]); if (dyp[m]) (void)hipFree(dyp[m]); }
     return rc;
 }
 

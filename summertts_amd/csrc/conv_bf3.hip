@@ -8,12 +8,13 @@ namespace sts {
 int tile_trace_bind_group(long long* buf, unsigned capacity_records);       // conv_bf3_group.hip
 int tile_trace_bind_resblock(long long* buf, unsigned capacity_records);    // resblock_bf3.hip
 int tile_trace_bind_flow(long long* buf, unsigned capacity_records);        // wn_flow.hip
+int tile_trace_bind_h2p(long long* buf, unsigned capacity_records);         // conv_h2p.hip
 static long long* g_tt_host_buf = nullptr;
 extern "C" int sts_debug_tile_trace(long long* buf, unsigned capacity_records) {
     // buf: device memory of (16 + 12 * capacity_records) 64-bit words (null: tracing off)
     g_tt_host_buf = buf;
     if (buf && hipMemset(buf, 0, 16 * sizeof(long long)) != hipSuccess) return -1;
-    if (tile_trace_bind(buf, capacity_records) || tile_trace_bind_group(buf, capacity_records) || tile_trace_bind_resblock(buf, capacity_records) || tile_trace_bind_flow(buf, capacity_records)) return -1;
+    if (tile_trace_bind(buf, capacity_records) || tile_trace_bind_group(buf, capacity_records) || tile_trace_bind_resblock(buf, capacity_records) || tile_trace_bind_flow(buf, capacity_records) || tile_trace_bind_h2p(buf, capacity_records)) return -1;
     return 0;
 }
 extern "C" int sts_debug_tile_trace_count() {

@@ -43,6 +43,7 @@ Engine::~Engine() {
 }
 
 static int default_conv_math();
+static constexpr int MAX_HALO_H2P = 64;      // conv_common.hpp MAX_HALO: the staged window of conv_h2p.hip
 // one polite spin-wait step on whatever host this is built for (the x86 builtin alone broke aarch64 / ppc64 builds)
 static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
@@ -791,7 +792,7 @@ int Engine::run_frame_workspace(RunCtx& c) {
     c.upS = upS;
     std::vector<size_t> stage_elems(M.n_up);
     size_t regA = 0, regB = 0;
-    { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)(1 + 3 * M.n_resk) * M.ups[i].Cout * Wcap * S;
+    { int S = 1; for (int i = 0; i < M.n_up; i++) { S *= M.up_rate[i]; stage_elems[i] = (size_t)(3 + 4 * M.n_resk) * M.ups[i].Cout * Wcap * S;   // upsampler output + 3 per chain (+ the pre-split path: planes / x16 of the stage input, one more per chain)
           if (i & 1) { if (stage_elems[i] > regB) regB = stage_elems[i]; } else { if (stage_elems[i] > regA) regA = stage_elems[i]; } } }
     const long Lsb = c.Lsb = Wcap * upS + B;           // MB-iSTFT: frames + 1 per window
     const int sbC = c.sbC = M.conv_post.Cout;
@@ -1044,6 +1045,17 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                 for (int k = 0; k < kAux; k++) (void)hipStreamWaitEvent(aux_[k], ev_fork_, 0);
             }
             static const bool no_fuse = exp_flag("STS_NO_FUSE");   // experiment knob
+            // the pre-split path (conv_h2p.hip) takes a stage only whole: between its layers the chains' tensors live in the x16 layout
+            bool h2p_stage = conv_math == 3 && h2p && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9;
+            for (int j = 0; j < nk && h2p_stage; j++) {
+                const DResBlock& rb = M.rb[(size_t)i * nk + j];
+                for (int d = 0; d < nd0 && h2p_stage; d++) {
+                    const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
+                    h2p_stage = c1.wh2p && c2.wh2p && c1.Cin == up.Cout && c1.Cout == up.Cout && c2.Cin == up.Cout && c2.Cout == up.Cout &&
+                                (c1.k & 1) && (c2.k & 1) && c1.dil >= 1 && c2.dil >= 1 && c1.pad == c1.dil * (c1.k - 1) / 2 && c2.pad == c2.dil * (c2.k - 1) / 2 &&
+                                c1.dil * (c1.k - 1) <= MAX_HALO_H2P && c2.dil * (c2.k - 1) <= MAX_HALO_H2P && !c1.depthwise && !c2.depthwise && !c1.transposed && !c2.transposed;
+                }
+            }
             for (int d = 0; d < nd0; d++) {
                 // narrow stages: the whole layer (conv1 -> lrelu -> conv2 -> + x) of all chains in one launch
                 ResLayerGroup R;
@@ -1107,6 +1119,47 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                     } else if (wino) resblock_wino(R, stream);
                     else resblock_layer(R, stream);
                     mfma_flops_ += fl; mfma_exec_ += wino ? flw : fl; mfma_launches_ += 1;
+                    continue;
+                }
+                // ---- round 6: the wide stages on pre-split, channel-minor activations (conv_h2p.hip).  The stage input is split once
+                // (planes P0 of lrelu(x) + the x16 copy X0 for the residual); conv1 reads planes and writes planes of lrelu(out); conv2 reads those
+                // and the x16 residual and writes the next layer's x16 + planes -- or, in the last layer, the fp32 [C][ld] tensor the next stage reads.
+                // Buffers: t1 (planes of conv1's output), pa / pb (x16 ping-pong, last layer: fp32), pn (planes of the layer output), per chain.
+                if (h2p_stage) {
+                    H2PGroup H1, H2;
+                    memset(&H1, 0, sizeof(H1)); memset(&H2, 0, sizeof(H2));
+                    H1.n = H2.n = nk; H1.seg = H2.seg = l2.seg; H1.B = H2.B = l2.nb; H1.max_n = H2.max_n = l2.max_len; H1.ovf = H2.ovf = ovf_;
+                    float* const P0 = reg + (size_t)(1 + 4 * nk) * ce; float* const X0 = P0 + ce;
+                    double fl = 0, f = 0;
+                    for (int j = 0; j < nk; j++) {
+                        const DResBlock& rb = M.rb[(size_t)i * nk + j];
+                        const DConv &c1 = rb.c1[d], &c2 = rb.c2[d];
+                        float *t1 = reg + (size_t)(1 + 3 * j) * ce, *pa = t1 + ce, *pb = pa + ce, *pn = reg + (size_t)(1 + 3 * nk + j) * ce;
+                        float* nxt = (cur[j] == pa) ? pb : pa;
+                        const bool last = d + 1 == nd0;
+                        {   // book FLOPs / algorithmic bytes exactly as for the two staged convs
+                            ConvOpt o1; o1.in_act = 1; o1.slope = 0.1f;
+                            (void)conv_args(c1, cur[j], l2, t1, l2, o1, &f); fl += f;
+                            ConvOpt o2; o2.in_act = 1; o2.slope = 0.1f; o2.res = cur[j]; o2.epi = EPI_RESADD;
+                            (void)conv_args(c2, t1, l2, nxt, l2, o2, &f); fl += f;
+                        }
+                        H2PArgs& a1 = H1.g[j];
+                        a1.xp = d == 0 ? (const void*)P0 : (const void*)pn; a1.xp_ld = l2.ld; a1.wb = c1.wh2p; a1.wscale = c1.h2_scale; a1.bias = c1.bias;
+                        a1.yp = t1; a1.yp_ld = l2.ld; a1.yp_slope = 0.1f;
+                        a1.Cin = c1.Cin; a1.Cout = c1.Cout; a1.ntap = c1.k; a1.tap_step = c1.dil; a1.tap_off = -c1.pad;
+                        H2PArgs& a2 = H2.g[j];
+                        a2.xp = t1; a2.xp_ld = l2.ld; a2.wb = c2.wh2p; a2.wscale = c2.h2_scale; a2.bias = c2.bias;
+                        a2.res16 = d == 0 ? X0 : cur[j]; a2.res_ld = l2.ld;
+                        if (last) { a2.y = nxt; a2.y_ld = l2.ld; }
+                        else { a2.y16 = nxt; a2.y16_ld = l2.ld; a2.yp = pn; a2.yp_ld = l2.ld; a2.yp_slope = 0.1f; }
+                        a2.Cin = c2.Cin; a2.Cout = c2.Cout; a2.ntap = c2.k; a2.tap_step = c2.dil; a2.tap_off = -c2.pad;
+                        cur[j] = nxt;
+                    }
+                    if (d == 0) split_planes(bup, l2.ld, up.Cout, l2.total, 0.1f, P0, X0, l2.ld, ovf_, stream);
+                    const int ht = h2p_tile < 0 ? -1 : (up.Cout == 128 ? (h2p_tile & 0xff) : ((h2p_tile >> 8) & 0xff));   // lab: low byte = the 128-channel stage, next = wider ones; 0xff = automatic
+                    conv_h2p_group(H1, stream, ht == 0xff ? -1 : ht);
+                    conv_h2p_group(H2, stream, ht == 0xff ? -1 : ht);
+                    mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_ += 2;
                     continue;
                 }
                 ConvGroup G1, G2; G1.n = G2.n = nk;

@@ -95,6 +95,8 @@ public:
     // noise scale is 0); the last kMemoEntries distinct utterances, FIFO
     static constexpr size_t kMemoEntries = 1024;
     std::unordered_map<unsigned long long, long> seen_tf_; std::deque<unsigned long long> seen_order_;
+    int h2p = 1;                       // 1: the wide ResBlock stages (C % 128 == 0) on pre-split channel-minor activations (conv_h2p.hip; two-term fp16 arithmetic only), 0: the staged kernels
+    int h2p_tile = -1;                 // lab: tile code of conv_h2p_group (-1: automatic)
     int flow_fused = 1;                // 1: the reverse flow as one launch per WaveNet layer where eligible (wn_flow.hip; two-term fp16 arithmetic only);
                                        // 0: one launch per conv (sts_debug_set STS_DBG_FLOW_FUSED)
     hipStream_t stream = nullptr;

@@ -238,6 +238,31 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 bool resblock_bf3_eligible(const ResLayerGroup& G);
 void resblock_bf3(const ResLayerGroup& G, hipStream_t st, int variant = -1);
 void conv_mfma_group(const ConvGroup& G, hipStream_t st, int tile = -1);
+
+// ---- two-term fp16 convs on PRE-SPLIT, channel-minor activations (conv_h2p.hip, round 6): the wide ResBlock stages of the decoder trunk.
+// The producer (the split kernel at a stage's entry, then every conv's own epilogue) applies the consumer's leaky relu, splits each value into
+// its two fp16 terms (conv_bf3_dev.hpp split8h) and stores them in the order the matrix core reads its operands in, so that a consumer's
+// input staging is a plain copy global -> LDS (buffer_load ... lds: no registers, no VALU work) instead of 8 dword loads + ~60 VALU + 2 LDS
+// stores per 32 positions x 16 channels.
+//   planes  [2 planes][C / 16 chunks][ld positions][2 units][8 fp16]    byte (p, c, t, h) = p * 2 C ld + (c ld + t) 32 + 16 h
+//   x16     [C / 16 chunks][ld positions][2 units][8 fp32]               the fp32 value itself (residual operand), same order
+//   element e of unit h of chunk c = channel 16 c + 8 (e >> 2) + 4 h + (e & 3)   (the accumulator rows one lane holds: bf3_pack perm_k)
+// A tensor in either layout takes 4 C ld bytes -- the size of the fp32 [C][ld] tensor it replaces.
+struct H2PArgs {
+    const void* xp; long xp_ld;           // input planes (C = Cin)
+    const void* wb; float wscale;         // bf3_pack(perm_k = true, math = 1) copy of the weights and the inverse of their power-of-two scale
+    const float* bias;                    // [Cout] or null
+    const float* res16; long res_ld;      // residual in x16 layout or null
+    float* y; long y_ld;                  // fp32 [Cout][y_ld] output or null (the last layer of a chain: what the next stage reads)
+    float* y16; long y16_ld;              // x16 output or null (the next layer's residual)
+    void* yp; long yp_ld; float yp_slope; // planes of lrelu(out, yp_slope) or null (the next conv's input)
+    int Cin, Cout, ntap, tap_step, tap_off;
+};
+struct H2PGroup { H2PArgs g[kMaxGroup]; int n; SegView seg; int B, max_n; unsigned* ovf; };   // g must stay the first member
+bool conv_h2p_group_eligible(const H2PGroup& G);
+void conv_h2p_group(const H2PGroup& G, hipStream_t st, int tile = -1);
+// fp32 [C][ld] -> planes of lrelu(x, slope) (+ the x16 copy when x16 != null); n = positions to convert (the packed total)
+void split_planes(const float* x, long x_ld, int C, long n, float slope, void* planes, float* x16, long out_ld, unsigned* ovf, hipStream_t st);
 void conv_generic(const ConvArgs& a, hipStream_t st);
 
 void embed(const int* ids, const float* emb, int vocab, int H, float scale, float* x, long ld, int total, hipStream_t st);

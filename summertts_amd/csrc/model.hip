@@ -223,6 +223,21 @@ bool pack_bf3(Store& st, DConv& d, bool perm_k = false) {
     return true;
 }
 
+// perm_k two-term fp16 copy alone (conv_h2p.hip: the pre-split path of the wide ResBlock stages consumes activations in the k order the
+// accumulator layout produces them in; both convs of a layer need it, at every width the path takes)
+bool pack_h2p(Store& st, DConv& d) {
+    if (d.wh2p || d.depthwise || d.transposed || !d.w || d.Cin != d.Cin_pad || d.Cout != d.Cout_pad || d.Cin != d.Cout || d.Cin % 128 != 0) return true;
+    const float* hptr = nullptr;
+    const size_t hbytes = bf3_pack(nullptr, 1, d.k, d.Cin_pad, d.Cout_pad, nullptr, true, 1);
+    float* q = st.alloc((hbytes + 3) / 4 + 2048, &hptr);
+    if (!q) return false;
+    const float* wh = st.host.data() + (d.w - st.dev);
+    float sc = 1.0f;
+    bf3_pack(wh, 1, d.k, d.Cin_pad, d.Cout_pad, q, true, 1, &sc);
+    d.wh2p = hptr; d.h2_scale = sc;
+    return true;
+}
+
 // Operands of wn_flow.hip for one coupling (see DFlowFused).  post is linear, so m = post(sum_l skip_l) = sum_l (W_post W_skip_l) acts_l + const:
 // the composite matrices are formed in double here, negated (the kernel accumulates -m and ADDS it to x1), and appended to each layer's
 // res rows.  All sources are the already packed fp32 copies, so the coupling's channel reversal (folded into pre / post) is in.
@@ -502,8 +517,8 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         const int n = r.geti();
         if (!r.ok || n <= 0 || n > 32) FAIL("resblock");
         rb.c1.resize(n); rb.c2.resize(n);
-        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i]) || !pack_wino(st, h, rb.c1[i]) || !pack_bf3(st, rb.c1[i])) FAIL("resblock convs1"); }
-        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i]) || !pack_bf3(st, rb.c2[i]) || !pack_bf3(st, rb.c2[i], true)) FAIL("resblock convs2"); }
+        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i]) || !pack_wino(st, h, rb.c1[i]) || !pack_bf3(st, rb.c1[i]) || !pack_h2p(st, rb.c1[i])) FAIL("resblock convs1"); }
+        for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i]) || !pack_bf3(st, rb.c2[i]) || !pack_bf3(st, rb.c2[i], true) || !pack_h2p(st, rb.c2[i])) FAIL("resblock convs2"); }
     }
     { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_post)) FAIL("conv_post"); }
     if (m.dec_type == 0 && m.is_ms == 1) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.dec_cond)) FAIL("decoder cond"); }

@@ -485,10 +485,11 @@ def chs_frontend_sections(tagger: bytes, verbalizer: bytes, jieba: Sequence[byte
     return np.frombuffer(bytes(out), dtype=np.float32).copy(), info
 
 
-def synthetic_ids(n: int, vocab: int, salt: int = 0) -> np.ndarray:
-    """Fixed seeded phoneme-id sequence: ids[i] = (i*37 + 11 + salt) mod vocab."""
+def synthetic_ids(n: int, vocab: int, salt: int = 0, family: int = 0) -> np.ndarray:
+    """Fixed seeded phoneme-id sequence: ids[i] = (i*37 + 11 + salt) mod vocab.  family > 0: another sequence of the same
+    length, ids[i] = (i*37 + 11 + salt + family * (i*i mod 101)) mod vocab -- bench.py's supply of requests an engine has not served before."""
     i = np.arange(n, dtype=np.int64)
-    return ((i * 37 + 11 + salt) % vocab).astype(np.int32)
+    return ((i * 37 + 11 + salt + family * ((i * i) % 101)) % vocab).astype(np.int32)
 
 
 def cfg_dict(cfg: ModelCfg) -> dict:

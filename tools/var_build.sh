@@ -11,7 +11,8 @@ SRCS=${VAR_SRC:-"conv_bf3.hip conv_bf3_group.hip resblock_bf3.hip"}
 O=summertts_amd/lib/obj
 for m in "$@"; do
   for s in $SRCS; do
-    /opt/rocm/bin/hipcc $F $VAR_EXTRA -DSTS_VAR=$m -c summertts_amd/csrc/$s -o summertts_amd/lib/var/${s%.hip}_$m$VAR_TAG.o &
+    FF="$F"; [ "$s" = conv_h2p.hip ] && FF="${F% -mllvm -amdgpu-mfma-vgpr-form}"     # (its 128 x 128 tiles need the AGPR half: Makefile FLAGS_conv_h2p)
+    /opt/rocm/bin/hipcc $FF $VAR_EXTRA -DSTS_VAR=$m -c summertts_amd/csrc/$s -o summertts_amd/lib/var/${s%.hip}_$m$VAR_TAG.o &
   done
 done
 wait
