@@ -332,6 +332,11 @@ def measure_config(eng, torch, n_cfg: int, conv_math: str, steps: int = 5, warmu
 
 
 def native_multi_bench(args) -> int:
+    print(json.dumps(native_multi_measure(args)), flush=True)
+    return 0
+
+
+def native_multi_measure(args) -> dict:
     """`--gpus N --multi native`: ONE process, sts_multi_create_ex(devices 0..N-1, STS_MULTI_RCCL) -- the library's own utterance sharding and
     RCCL gather (ncclAllGather of the counts, ncclSend / grouped ncclRecv of the int16 PCM to device 0, one download): the code a C++ caller
     of the drop-in library gets, which the torch.distributed path of the default `--gpus N` does not exercise.  Same JSON
@@ -399,8 +404,7 @@ def native_multi_bench(args) -> int:
         "note": "roofline / cpu_baseline: see the N = 1 line (sts_multi does not expose per-engine profiles)",
     }
     md.close()
-    print(json.dumps(out), flush=True)
-    return 0
+    return out
 
 
 def _env_conv_math() -> str:
@@ -450,6 +454,9 @@ def main():
     ap.add_argument("--multi", default="torch", choices=["torch", "native"],
                     help="--gpus N > 1: torch = one process per GPU, torch.distributed gather (the default, what a launcher starts); native = ONE process, "
                          "sts_multi_create_ex(devices 0..N-1, STS_MULTI_RCCL): the library's own RCCL gather, the code a C++ caller gets")
+    ap.add_argument("--multi-leg", default="on", choices=["on", "off"],
+                    help="--gpus N > 1 under --multi torch: after the distributed run, rank 0 also measures the library's native RCCL gather in-process and "
+                         "appends it as `multi_native` (on by default: one SCALE invocation measures both gathers)")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
                     help="lab use: sts_debug_set on the timed engine, e.g. tile_claim=0 (A/B of a dispatch choice in one process / on one box)")
     ap.add_argument("--pipeline-engines", type=int, default=2,
@@ -600,7 +607,7 @@ def main():
     drain()
     # the timed steps record only the two HIP events that bracket the matrix-core region (the dominant kernel family, timed inside the timed
     # region as the contract asks); the per-stage breakdown comes from a separate leg below -- each stage event is a barrier packet between
-    # two kernels and the eight of them cost the step ~20-30 us
+    # two kernels and the eight of them cost the step ~20-30 us (docs/HISTORY.md 12-4)
     try:
         syn.set_profiling(args.timed_profiling)
     except Exception:
@@ -785,14 +792,21 @@ def main():
             for t_ in [pool.submit(ids[0], sid[0], ls[0]) for _ in range(2 * args.pipeline_engines)]:
                 pool.wait(t_)                                    # warm-up: every engine has run once
             rounds = []                                          # three rounds of nreq requests: the median one is reported (one round of
-            for _ in range(3):                                   # 20 requests is 40 ms: a single host hiccup used to decide the figure)
+            cpu0, wall0 = time.process_time(), time.perf_counter()
+            for r_i in range(3):                                 # 20 requests is 40 ms: a single host hiccup used to decide the figure)
+                # requests the pool's engines have NOT served before (a family of id sequences per round): its workers wait for every frame count
+                req = [sb.synthetic_ids(len(ids[u % len(ids)]), cfg.vocab, salt=u, family=500 + 37 * r_i + (0 if mb == 1 else 1000)) for u in range(nreq)]
                 tp0 = time.perf_counter()
-                tk = [pool.submit(ids[u % len(ids)], sid[u % len(ids)], ls[u % len(ids)]) for u in range(nreq)]
+                tk = [pool.submit(req[u], sid[u % len(ids)], ls[u % len(ids)]) for u in range(nreq)]
                 done = sum(int(pool.wait(t_).size) for t_ in tk)
                 rounds.append((time.perf_counter() - tp0, done))
+            cores = (time.process_time() - cpu0) / max(1e-9, time.perf_counter() - wall0)
             tp, done = sorted(rounds)[1]
             pipelined[label] = {"value": done / tp, "unit": "samples/s", "x_realtime_16khz": done / tp / 16000.0,
-                                "ms_per_request": 1e3 * tp / nreq, "ms_per_request_rounds": [round(1e3 * r_[0] / nreq, 3) for r_ in rounds]}
+                                "ms_per_request": 1e3 * tp / nreq, "ms_per_request_rounds": [round(1e3 * r_[0] / nreq, 3) for r_ in rounds],
+                                "host_cores_busy": cores,
+                                "host_cores_busy_definition": "process CPU time / wall time over the three rounds (submitting thread + every pool worker): the workers sleep "
+                                                              "through most of the wait for a new request's frame counts instead of polling it (engine.hip wait_frame_counts)"}
             pool.close()
 
     total_samples = samples
@@ -1004,6 +1018,22 @@ def main():
         if gq is not None:
             gq.put(None)
         dist.destroy_process_group()
+    # One SCALE invocation measures BOTH gathers: after the one-process-per-GPU run (torch.distributed gather) rank 0 drives
+    # all N devices through the library's own sharding + RCCL gather (sts_multi_create_ex(0..N-1, STS_MULTI_RCCL): what a C++ caller of the drop-in
+    # gets) in this process and appends the figures to the same line.  The other ranks have left their GPUs by then or are about to; a failure of
+    # this leg never costs the line its headline.
+    if result_line is not None and world > 1 and args.multi_leg != "off":
+        try:
+            syn.close()
+            nat = native_multi_measure(args)
+            out["multi_native"] = {"value": nat["value"], "unit": nat["unit"], "ms_per_step": nat["ms_per_step"], "n_gpus": nat["n_gpus"],
+                                   "rccl_ranks": nat["multi_gpu"]["rccl_ranks"], "gather_mode": nat["multi_gpu"]["gather_mode"],
+                                   "gather_ms_per_step": nat["multi_gpu"]["gather_ms_per_step_rank0"], "samples_per_device": nat["multi_gpu"]["samples_per_device"],
+                                   "note": "the same global batch through ONE process and the library's native RCCL gather (sts_multi), measured right after the "
+                                           "torch.distributed run of this line; `value` of the line stays the one-process-per-GPU figure"}
+        except Exception as e:      # noqa: BLE001
+            out["multi_native"] = {"error": f"{type(e).__name__}: {e}"}
+        result_line = json.dumps(out)
     if result_line is not None:      # the JSON line is the LAST thing on stdout (RCCL may print banners earlier)
         sys.stdout.flush()
         print(result_line, flush=True)

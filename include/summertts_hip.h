@@ -119,7 +119,7 @@ int sts_set_conv_mode(sts_engine* e, int mode);
  *       those switch to the split form only from the batch size on at which they stop being launch-latency-bound (tests).
  *   3 = "f16x2": fp32 operands as TWO fp16 terms (the small one pre-scaled by 2^11, weights by a per-conv power of two), three
  *       fp16 MFMA products per fp32 product -- half the matrix-pipe time of 0, 22-23 instead of 24 operand bits (measured error
- *       against float64: DESIGN.md 5f) -- the default.  An activation beyond fp16's range raises a flag and the call (a
+ *       against float64: docs/HISTORY.md 5f) -- the default.  An activation beyond fp16's range raises a flag and the call (a
  *       streaming call: the chunk, before it is handed out) is repeated in form 0; sts_profile.conv_math_fallbacks counts these.
  *       After two such calls in a row the engine stays in form 0 until sts_set_conv_math is called again
  *       (sts_profile.conv_math_pinned).  The first repeat of an engine and the pinning are reported through tts_log.
@@ -133,13 +133,15 @@ int sts_set_conv_math(sts_engine* e, int mode);
  *   (Keys 2-4 selected the two persistent-kernel families of round 3; both lost their A/B against the launch path and were deleted
  *   in round 5 -- the numbers stay retired and answer STS_EINVAL.) */
 enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1,
-       STS_DBG_H2P = 11 /* decoder stages of 128 k channels under the two-term fp16 arithmetic: 1 (default) pre-split channel-minor activations (conv_h2p.hip), 0 the staged kernels */,
+       STS_DBG_TAIL_FUSED = 14 /* MB-iSTFT / MS-iSTFT decoders: 1 (default) the tail (spectrum, inverse DFT + overlap-add, synthesis filter, int16 cast) as one launch, 0 three */,
+       STS_DBG_CHAIN_STREAMS = 13 /* lab: bit i = the ResBlock chains of decoder stage i as per-chain launches on three prioritised streams instead of one grouped launch per layer (-1: off) */,
+       STS_DBG_H2P = 11 /* decoder stages of 128 k channels under the two-term fp16 arithmetic: 1 (default) pre-split channel-minor activations (conv_h2p.hip) from ~8 tiles of 128 x 128 per CU on, 2 always (tests), 0 the staged kernels */,
        STS_DBG_H2P_TILE = 12 /* lab: tile code of conv_h2p_group, -1 automatic */,
        STS_DBG_MEMO_CLEAR = 10 /* any value: forget the launch-ahead memo (bench.py: every timed request is then one the engine has not served before) */,
        STS_DBG_PCM_DIRECT = 9 /* sts_set_host_pcm(1), one utterance: 1 (default) the decoder's last kernel writes the PCM into the pinned host buffer itself, 0 a download behind it */,
        STS_DBG_DDS_TAIL = 8 /* stochastic duration predictor: 1 (default) a ConvFlow's projection + spline step ride in its last DDSConv layer's launch, 0 three launches */,
        STS_DBG_ATTN_REG = 7 /* one-query attention: 1 (default) operands in registers (attention_reg_kernel), 0 the round-1 kernel */,
-       STS_DBG_LAUNCH_AHEAD = 6 /* one-utterance calls: 1 (default) a request the engine has served before (same ids, speaker, length scale: the frame count is a pure function of them) enqueues flow + decoder before the count reaches the host, 0 the host always waits for it, 2 (tests) the memo is keyed by the phoneme count alone -- provokes the repeat that answers a hash collision */,
+       STS_DBG_LAUNCH_AHEAD = 6 /* one-utterance calls and packed batches: 1 (default) a request the engine has served before (same ids, speaker, length scale: the frame count is a pure function of them) enqueues flow + decoder before the count reaches the host, 0 the host always waits for it, 2 (tests) the memo is keyed by the phoneme count alone -- provokes the repeat that answers a hash collision */,
        STS_DBG_FLOW_FUSED = 5 /* reverse flow: 1 (default) one launch per WaveNet layer (wn_flow.hip, under the two-term fp16 arithmetic), 0 one launch per conv */ };
 int sts_debug_set(sts_engine* e, int key, int value);
 
@@ -160,8 +162,8 @@ typedef struct sts_profile {
                                              (6 x their algorithmic FLOPs; 3 x with sts_set_conv_math(3)); 0 with sts_set_conv_math(1) */
     int64_t conv_math_fallbacks;          /* sts_set_conv_math(3): calls of this engine so far that were repeated in the split-bf16 form */
     int32_t conv_math_pinned;             /* 1: after two such calls in a row the engine now stays in the split-bf16 form (until sts_set_conv_math) */
-    int32_t launch_ahead;                 /* 1: this run enqueued flow + decoder before the frame count reached the host (one utterance; ms_sync_wait_host ~ 0) */
-    int64_t launch_ahead_misses;          /* launch-ahead runs of this engine so far whose frame count fell outside the predicted 64-frame bucket (flow + decoder repeated) */
+    int32_t launch_ahead;                 /* 1: this run enqueued flow + decoder before the frame count reached the host (one utterance or a packed batch whose members the engine has all served before; ms_sync_wait_host ~ 0) */
+    int64_t launch_ahead_misses;          /* launch-ahead runs of this engine so far (one utterance or a batch) whose remembered frame counts turned out wrong -- a hash collision of the memo -- so that flow + decoder were repeated the waiting way */
     float us_host_setup;                  /* host time from the entry of the run to the first launch being enqueued (input checks, tables, the one upload) */
     float us_host_enqueue;                /* host time from the entry of the run to the last launch being enqueued (the GPU runs behind it) */
     float us_host_tail;                   /* host time from the return of the run's last stream synchronisation to the return of the call */

@@ -24,6 +24,27 @@ PORT_SO = os.path.join(HERE, "libvits_oracle.so")
 REFERENCE_ROOT = "/root/reference"
 
 
+# The checkers parallelise with OpenMP.  On a many-core host (the GPU box: 256 CPUs) libgomp's default -- one thread per CPU, each spinning
+# between parallel regions -- turns a tiny model's thousands of short loops into minutes of wall time and ~16 cores of pure spinning next
+# to the HIP runtime's own threads (round 6: tests/fake_rccl/three_ranks.py took 8 m 45 s of a 12-minute GPU suite, 137 CPU-minutes).  The
+# team is capped at 16 threads when the first model is created (omp_set_num_threads: works whether or not libgomp is already loaded), unless
+# the user chose OMP_NUM_THREADS; bench.py's cpu_baseline leg sets the team size it measures with explicitly afterwards.
+_omp_capped = False
+
+
+def _cap_omp_threads() -> None:
+    global _omp_capped
+    if _omp_capped or os.environ.get("OMP_NUM_THREADS"):
+        return
+    _omp_capped = True
+    for name in ("libgomp.so.1", "libgomp.so"):
+        try:
+            C.CDLL(name, mode=C.RTLD_GLOBAL).omp_set_num_threads(int(min(16, os.cpu_count() or 1)))
+            return
+        except OSError:
+            continue
+
+
 def build(port: bool = True, ref: bool = True, quiet: bool = True) -> None:
     """Compile the checkers (ref only when /root/reference exists: it does not on the GPU box)."""
     targets = []
@@ -51,6 +72,7 @@ class _Model:
 
     def __init__(self, so: str, prefix: str, blob: np.ndarray):
         self.lib = C.CDLL(so)
+        _cap_omp_threads()
         self.p = prefix
         f = self._f
         f("create").restype = C.c_void_p

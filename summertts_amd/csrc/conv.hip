@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_mfma_group_kernel(ConvGroup 
 //
 // This single-conv kernel is reachable through sts_debug_conv1d(mode 12) (tests, tools/conv_bench.py); the product
 // path uses the same arithmetic inside the fused layer kernel below (resblock_wino_kernel).  Measured on MI355X
-// (DESIGN.md 5): as a single conv it beats the direct kernel by 11-21 % on the 128/64/32-channel decoder shapes.
+// (docs/HISTORY.md 5): as a single conv it beats the direct kernel by 11-21 % on the 128/64/32-channel decoder shapes.
 //
 // A dilated k-tap conv computes the output pair (y[n], y[n+d]) from x[n + j d], j = 0..k.  Cutting the taps
 // into 3-tap (and 2-tap) segments and applying the minimal-filtering identity F(2,3) to each segment,

@@ -12,7 +12,7 @@
 // and accumulates in fp32.  The three products of relative order 2^-24 and below (mid*lo, lo*mid, lo*lo) are dropped --
 // that is the size of the rounding error an fp32 multiply-add makes anyway -- leaving SIX bf16 MFMAs per fp32 MFMA-equivalent:
 // 6/16 of the matrix-pipe time of the exact-fp32 instruction.  Measured against fp64 the result is as accurate as the
-// fp32 MFMA kernels' (tests/test_parity_gpu.py::test_bf3_conv_*); every parity tolerance is unchanged.
+// fp32 MFMA kernels' (tests/test_parity_gpu.py::test_bf3_conv_*; docs/HISTORY.md 5d); every parity tolerance is unchanged.
 //
 // Layout follows from the instruction: a lane feeds 8 CONSECUTIVE k values (input channels) of one row / column.
 //   * weights are split and fragment-packed at load time (bf3_pack): [phase][chunk of 16 cin][tap][32-row tile][plane][lane][8],

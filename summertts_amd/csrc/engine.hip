@@ -5,6 +5,7 @@
 // Everything runs on the engine's own HIP stream; the only host synchronisation inside a run is the
 // data-dependent frame count F (SynthesizerTrn.cpp:376-381).
 #include "engine.hpp"
+#include <time.h>
 #include "knobs.hpp"
 #include "../../include/tts_logger.h"
 
@@ -36,6 +37,7 @@ Engine::~Engine() {
     if (have_events_) {
         for (auto& e : ev_) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_fork_);
+        if (ev_setup_) (void)hipEventDestroy(ev_setup_);
         for (auto& e : ev_join_) (void)hipEventDestroy(e);
         for (auto& a : aux_) if (a) (void)hipStreamDestroy(a);
     }
@@ -66,6 +68,7 @@ int Engine::init(const float* blob, int64_t bytes, int dev) {
     HIPCK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& e : ev_) HIPCK(hipEventCreate(&e));
     HIPCK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&ev_setup_, hipEventDisableTiming));
     for (auto& e : ev_join_) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     {   // the chain with the largest kernel size (most FLOPs) is the critical path of a decoder stage:
         // give it the highest queue priority, the lightest chain the lowest
@@ -108,7 +111,7 @@ bool Engine::ensure_pinned(size_t bytes) {
 void Engine::stage_begin(int s) { cur_stage_ = s; }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // profiling 1: all eight stage events; 2: only the two that bracket the decoder's matrix-core region (events 5 / 6) -- every event is a barrier
-// packet between two kernels (5-10 us of bubble each), so the headline step pays for two of them, not eight
+// packet between two kernels (5-10 us of bubble each, docs/HISTORY.md 12-4), so the headline step pays for two of them, not eight
 void Engine::mark(int i) { if (profiling == 1 || (profiling == 2 && (i == 5 || i == 6))) (void)hipEventRecord(ev_[i], stream); }
 
 // builds the kernel arguments of one conv and books its FLOPs / minimum HBM bytes
@@ -463,6 +466,7 @@ int Engine::run_setup(RunCtx& c) {
     int* p_forced = p_ids + Ttot;
     if (have_forced) memcpy(p_forced, forced_dur.data(), sizeof(int) * Ttot);
     HIPCK(hipMemcpyAsync(bt.meta_i, pm, (meta_ints + B + (size_t)Ttot * (have_forced ? 2 : 1)) * 4, hipMemcpyHostToDevice, stream));
+    if (B > 1) HIPCK(hipEventRecord(ev_setup_, stream));     // (run_durations, batches launched from the memo: the host rewrites part of this block)
 
     // single-segment views travel by value (kernels.hpp SegView): no segment-table load in the kernels of a one-utterance call
     static const bool no_inline_seg_knob = exp_flag("STS_NO_INLINE_SEG");   // experiment knob
@@ -485,7 +489,7 @@ int Engine::run_text_encoder(RunCtx& c) {
     // the FFN's split-K partials) afterwards -- runs inside the launch of the first conv that consumes x (col_proj_kernel)
     // where the width is instantiated and the grid is small; otherwise as its own launch.
     static const bool no_colp = exp_flag("STS_NO_COL_LAYER") || exp_flag("STS_NO_COL_PROJ");   // experiment knobs
-    // Measured (profiles/r02 notes in DESIGN.md 5b): with a handful of column blocks (one 128-phoneme utterance = 8) a
+    // Measured (profiles/r02 notes in docs/HISTORY.md 5b): with a handful of column blocks (one 128-phoneme utterance = 8) a
     // three-pass q/k/v projection makes each of the few workgroups pull 3 x 147 KB of weights through one CU and loses to
     // the separate LayerNorm + chip-wide conv (23 vs 18 us); from a few dozen blocks on it wins (batch 8: -12 us per layer).
     // A single-pass conv (the encoder's output projection) wins at every size.
@@ -632,7 +636,7 @@ int Engine::run_durations(RunCtx& c) {
     // count from device memory, where the durations kernel leaves it (clamped to the capacity).  The host never waits between the duration
     // predictor and the flow; it reads the count after the last kernel is enqueued and sizes the PCM download with it.
     // The prediction is a MEMO, not a guess (round 5): the reference's noise scale is hard-coded 0 (SynthesizerTrn.cpp:357), so the
-    // frame count is a pure function of (phoneme ids, speaker, length scale); the engine remembers the count of its last 64 distinct
+    // frame count is a pure function of (phoneme ids, speaker, length scale); the engine remembers the count of its last 1 024 distinct (engine.hpp kMemoEntries)
     // requests under a 64-bit hash of exactly those inputs.  A request it has seen runs ahead with the exact count -- never more than the
     // 63 frames of bucket padding the waiting path also carries, never a miss; any other request takes the waiting path.  Should the
     // count land in another 64-frame bucket than predicted (a hash collision), the two stages are repeated the waiting way, so the samples a
@@ -681,6 +685,9 @@ int Engine::run_durations(RunCtx& c) {
         return frame_geometry(c);
     }
     if (c.ahead_b) {                                    // the batch's geometry from the memo; checked against the kernel's counts in run_output
+        // p_offF / p_lenF live in the pinned block run_setup uploaded: that copy (issued ~0.3 ms of host work ago) must have read them before the
+        // host rewrites them (nothing enforced it)
+        HIPCK(hipEventSynchronize(ev_setup_));
         c.Ftot = 0; c.maxF = 0;
         for (int b = 0; b < B; b++) {
             const int f = (int)c.predF[b];
@@ -693,6 +700,36 @@ int Engine::run_durations(RunCtx& c) {
     return frame_geometry(c);
 }
 
+static inline int wait_class(long phonemes) { int c = 0; while ((1L << (c + 1)) <= phonemes && c < 23) c++; return c; }
+void Engine::nap_before_wait(int which, long phonemes) {
+    if (!polite_wait) return;
+    const WaitEst& e = wait_est_[which][wait_class(phonemes)];
+    if (e.us <= 0.0 || e.phonemes <= 0) return;
+    const double scale = phonemes < e.phonemes ? (double)phonemes / (double)e.phonemes : 1.0;      // (a smaller request of the class: never oversleep it)
+    const double nap = e.us * scale * 0.8 - 70.0;            // (less the timer slack of a normal thread)
+    if (nap < 40.0) return;
+    struct timespec ts; ts.tv_sec = (time_t)(nap * 1e-6); ts.tv_nsec = (long)((nap - (double)ts.tv_sec * 1e6) * 1e3);
+    (void)nanosleep(&ts, nullptr);
+}
+void Engine::note_wait(int which, long phonemes, double waited_us, bool was_ready_at_wake) {
+    if (!polite_wait) return;
+    WaitEst& e = wait_est_[which][wait_class(phonemes)];
+    // ready at the first look after the nap = the estimate is too long (by an unknown amount): shrink it; otherwise the wait was measured
+    if (e.us <= 0.0) { e.us = waited_us * 0.5; e.phonemes = phonemes; }
+    else if (was_ready_at_wake) e.us *= 0.85;
+    else { e.us = e.us * 0.7 + waited_us * 0.3; e.phonemes = phonemes; }
+}
+// the run's one stream synchronisation
+int Engine::final_sync(long phonemes) {
+    if (!polite_wait) { HIPCK(hipStreamSynchronize(stream)); return STS_OK; }
+    const double t0 = now_us();
+    nap_before_wait(1, phonemes);
+    const bool ready = hipStreamQuery(stream) == hipSuccess;
+    HIPCK(hipStreamSynchronize(stream));
+    note_wait(1, phonemes, now_us() - t0, ready);
+    return STS_OK;
+}
+
 // blocks until the durations kernel's results are on the host: durations_h, per-utterance frame offsets / counts, Ftot, maxF
 int Engine::wait_frame_counts(RunCtx& c) {
     const int B = c.B; const long Ttot = c.Ttot; BufT& bt = c.bt;
@@ -700,13 +737,15 @@ int Engine::wait_frame_counts(RunCtx& c) {
     int* p_down = (int*)(pinned_ + c.up_bytes);
     {
         const auto w0 = std::chrono::steady_clock::now();
+        bool polled_unready = true;
         if (c.mapped) {
             volatile int* flag = hmap_;                 // word 0 = sequence flag, then dur[Ttot], frames[B]
             bool ok = false;
-            // a short pure spin (the usual wait is a fraction of a millisecond), then polite polling -- pool / multi-device
-            // workers must not each burn a core for a whole batch --, and after 50 ms a plain stream synchronisation
+            polled_unready = false;
+            // (sts_pool / sts_multi workers sleep through most of this wait: engine.hpp polite_wait)
+            nap_before_wait(0, Ttot);
             for (long spin = 0; ; spin++) {
-                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_) { ok = true; break; }
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_) { ok = true; polled_unready = spin > 0; break; }
                 cpu_relax();
                 if (spin >= 20000) std::this_thread::yield();
                 if ((spin & 0x3ff) == 0x3ff) {      // every ~1k polls: did the stream die?  (a kernel fault would spin forever)
@@ -726,7 +765,9 @@ int Engine::wait_frame_counts(RunCtx& c) {
             HIPCK(hipMemcpyAsync(p_down, bt.dur, ((size_t)Ttot + B) * 4, hipMemcpyDeviceToHost, stream));
             HIPCK(hipStreamSynchronize(stream));
         }
-        sync_wait_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        const double waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        sync_wait_ms_ += waited_ms;
+        if (c.mapped) note_wait(0, Ttot, waited_ms * 1e3, !polled_unready);
     }
     durations_h.assign(p_down, p_down + Ttot);
     tap("logw", bt.dlogw, 1, Ttot, Ttot);
@@ -1030,7 +1071,8 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             for (int j = 0; j < nk; j++) cur[j] = bup;
             // experiment knob STS_CHAIN_STREAMS=<stage mask>: the chains of the masked stages go out as per-chain launches on
             // the prioritised auxiliary streams (heaviest chain first) instead of one grouped launch per layer
-            static const int chain_streams = exp_int("STS_CHAIN_STREAMS", 0);
+            static const int chain_streams_env = exp_int("STS_CHAIN_STREAMS", 0);
+            const int chain_streams = chain_streams_dbg >= 0 ? chain_streams_dbg : chain_streams_env;     // (lab: sts_debug_set STS_DBG_CHAIN_STREAMS)
             const bool per_chain = ((chain_streams >> i) & 1) && nk <= kAux;
             int crank[kMaxGroup];
             for (int j = 0; j < nk; j++) {
@@ -1046,7 +1088,11 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             }
             static const bool no_fuse = exp_flag("STS_NO_FUSE");   // experiment knob
             // the pre-split path (conv_h2p.hip) takes a stage only whole: between its layers the chains' tensors live in the x16 layout
-            bool h2p_stage = conv_math == 3 && h2p && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9;
+            // Measured (profiles/r06_h2p_engine_ab.log): -1.4 % of the step at 32 HiFi-GAN utterances, -3.0 % at 64 MB-iSTFT ones, +6 % at ONE utterance
+            // (the entry split is a launch of its own, the second conv of a layer writes two tensors, and a grid of one tile per CU gains nothing
+            // from a faster K loop): taken from ~8 tiles of 128 x 128 per CU on.  h2p == 2 (lab): always.
+            const long h2p_tiles = (long)((l2.max_len + 127) / 128) * (up.Cout / 128) * l2.nb * nk;
+            bool h2p_stage = conv_math == 3 && h2p && (h2p == 2 || h2p_tiles >= 2048) && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9;
             for (int j = 0; j < nk && h2p_stage; j++) {
                 const DResBlock& rb = M.rb[(size_t)i * nk + j];
                 for (int d = 0; d < nd0 && h2p_stage; d++) {
@@ -1066,7 +1112,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                 static const bool bf3_nofuse = exp_flag("STS_BF3_NOFUSE");   // experiment knob
                 const bool bf3_layer = (conv_math != 1) && !bf3_nofuse;
                 // split-bf16 arithmetic: the 64/32-channel stages always run fused; the 128-channel stage (whole window = 147 KB of
-                // LDS, one 8-wave workgroup per CU) from ~8 tiles per CU on -- the trunk is power-bound at batch, so
+                // LDS, one 8-wave workgroup per CU) from ~8 tiles per CU on -- the trunk is power-bound at batch (docs/HISTORY.md 5d), so
                 // dropping the intermediate's HBM round trip pays (batch 8: -3 %), while a single utterance's 1 089 tiles on 256
                 // workgroup slots only tie the unfused pair
                 static const int bf3_fuse128_tiles = exp_int("STS_BF3_FUSE128_TILES", 2048);   // experiment knob
@@ -1107,7 +1153,9 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                     const bool wino = !no_wino && resblock_wino_eligible(R);
                     if (bf3_layer && resblock_bf3_eligible(R)) {
                         static const int bv = exp_int("STS_BF3_LAYER_VARIANT", -1);   // experiment knob
-                        resblock_bf3(R, stream, bv);
+                        if (per_chain) {
+                            for (int j = 0; j < nk; j++) { ResLayerGroup R1 = R; R1.n = 1; R1.g[0] = R.g[j]; resblock_bf3(R1, aux_[crank[j] % kAux], bv); }
+                        } else resblock_bf3(R, stream, bv);
                         mfma_flops_ += fl; bf16_exec_ += products() * fl; mfma_launches_ += 1;
                         continue;
                     }
@@ -1181,10 +1229,13 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                 if (per_chain) {
                     for (int j = 0; j < nk; j++) {
                         hipStream_t cs = aux_[crank[j] % kAux];
-                        if (conv_mfma_eligible(G1.g[j])) conv_mfma(G1.g[j], cs, gtile); else conv_generic(G1.g[j], cs);
-                        if (conv_mfma_eligible(G2.g[j])) conv_mfma(G2.g[j], cs, gtile); else conv_generic(G2.g[j], cs);
+                        for (const ConvArgs* ca : {&G1.g[j], &G2.g[j]}) {
+                            if (conv_math != 1 && conv_bf3_eligible(*ca)) conv_bf3(*ca, cs, -1);
+                            else if (conv_mfma_eligible(*ca)) conv_mfma(*ca, cs, gtile);
+                            else conv_generic(*ca, cs);
+                        }
                     }
-                    mfma_flops_ += fl1 + fl2; mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
+                    mfma_flops_ += fl1 + fl2; if (conv_math != 1) bf16_exec_ += products() * (fl1 + fl2); else mfma_exec_ += fl1 + fl2; mfma_launches_ += 2;
                     continue;
                 }
                 if ((conv_math != 1) && conv_bf3_group_eligible(G1) && conv_bf3_group_eligible(G2)) {
@@ -1262,9 +1313,18 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
         ConvOpt o; o.in_act = 1; o.slope = 1e-2f; o.reflect = 1;
         with_mean(o);
         conv(M.conv_post, x, lx, bf.tailA, lsb, o);
-        istft_spectrum(bf.tailA, lsb.ld, sbC, bf.tailB, lsb.total, stream);
         const int bands = M.dec_type == 2 ? 1 : 4;
         const Lvl ltm = lvF(S * 4, 0);
+        if (tail_fused && M.dec_type != 2 && sbC == 72 && istft_tail_fused_ok(bands, M.fir_taps, M.fir_pad)) {
+            // spectrum + inverse DFT / overlap-add + synthesis filter + int16 cast in one launch (misc_kernels.hip istft_tail_fused_kernel)
+            const Lvl lo = lvF(S * 16, 0);
+            istft_tail_fused(bf.tailA, lsb.ld, lsb.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, M.fir_bias, wave, bf.pcm, lo.seg, nw, ltm.max_len, stream);
+            flops_[3] += 2.0 * (double)Ntot * (16.0 * 4 + 4 * 18 * 4 / 4.0);
+            mark(4);
+            if (wave) tap("wave", wave, 1, Ntot, (wlen0 >= 0 ? (long)wlen0 : Wtot) * hop);
+            return STS_OK;
+        }
+        istft_spectrum(bf.tailA, lsb.ld, sbC, bf.tailB, lsb.total, stream);
         float* tm = bf.tailC;
         istft_ola(bf.tailB, lsb.ld, bands, 18, lsb.seg, tm, ltm.ld, ltm.seg, nw, ltm.max_len, stream);
         if (M.dec_type == 2) {
@@ -1272,7 +1332,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             if (wave) HIPCK(hipMemcpyAsync(wave, tm, (size_t)Ntot * 4, hipMemcpyDeviceToDevice, stream));
         } else {
             const Lvl lo = lvF(S * 16, 0);
-            synth_fir(tm, ltm.ld, ltm.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, M.dec_type == 1 ? M.fir_bias : 0.f, wave, bf.pcm, lo.seg, nw,
+            synth_fir(tm, ltm.ld, ltm.seg, M.synth_fir, M.fir_taps, M.fir_pad, (float)M.subbands, M.fir_bias /* 0 unless the blob's learned filter carries one (MS); the PQMF bank has none */, wave, bf.pcm, lo.seg, nw,
                       ltm.max_len, stream);
         }
         flops_[3] += 2.0 * (double)Ntot * (16.0 * 4 + 4 * 18 * 4 / 4.0);
@@ -1368,7 +1428,7 @@ int Engine::run_output(RunCtx& c) {
             // stream synchronisation happens before the count is looked at: the host never waits for the count by itself
             if (host_pcm && !pcm_in_host_) HIPCK(hipMemcpyAsync(pinned_pcm_, bf.pcm, (size_t)Fld * hop * 2, hipMemcpyDeviceToHost, stream));
             host_us_enq_ = (float)(now_us() - host_t0_);
-            HIPCK(hipStreamSynchronize(stream));
+            if ((rc = final_sync(c.Ttot)) != STS_OK) return rc;
             host_t_sync_ = now_us();
             if ((rc = wait_frame_counts(c)) != STS_OK) return rc;
             if ((c.Ftot + 63) / 64 * 64 != Fld) {
@@ -1397,7 +1457,7 @@ int Engine::run_output(RunCtx& c) {
         }
         if (!ahead) {
             host_us_enq_ = (float)(now_us() - host_t0_);
-            HIPCK(hipStreamSynchronize(stream));
+            { const int rcs = final_sync(c.Ttot); if (rcs != STS_OK) return rcs; }
             host_t_sync_ = now_us();
         }
         if (c.ahead_b) {

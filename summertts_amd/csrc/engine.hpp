@@ -95,6 +95,18 @@ public:
     // noise scale is 0); the last kMemoEntries distinct utterances, FIFO
     static constexpr size_t kMemoEntries = 1024;
     std::unordered_map<unsigned long long, long> seen_tf_; std::deque<unsigned long long> seen_order_;
+    // Host waits of a run (the frame counts of a request the engine has not served before; the run's final stream synchronisation).  A direct
+    // caller's thread polls them (lowest latency: it asked for one utterance now).  sts_pool / sts_multi workers set polite_wait: their thread
+    // SLEEPS through ~80 % of the expected wait and polls only the tail, so N engines do not cost N host cores.  The
+    // expectation is a running estimate per size class (log2 of the batch's phoneme count), scaled down for a smaller request of the class.
+    bool polite_wait = false;
+    struct WaitEst { double us = 0.0; long phonemes = 0; };
+    WaitEst wait_est_[2][24];              // [0] frame counts, [1] final synchronisation
+    void nap_before_wait(int which, long phonemes);
+    void note_wait(int which, long phonemes, double waited_us, bool was_ready_at_wake);
+    int final_sync(long phonemes);
+    int tail_fused = 1;                // MB-iSTFT / MS-iSTFT tail: 1 spectrum + inverse DFT / overlap-add + synthesis filter + int16 cast as one launch, 0 three (sts_debug_set)
+    int chain_streams_dbg = -1;        // lab: stage mask -- the chains of the masked decoder stages as per-chain launches on three prioritised streams instead of grouped launches
     int h2p = 1;                       // 1: the wide ResBlock stages (C % 128 == 0) on pre-split channel-minor activations (conv_h2p.hip; two-term fp16 arithmetic only), 0: the staged kernels
     int h2p_tile = -1;                 // lab: tile code of conv_h2p_group (-1: automatic)
     int flow_fused = 1;                // 1: the reverse flow as one launch per WaveNet layer where eligible (wn_flow.hip; two-term fp16 arithmetic only);
@@ -139,6 +151,7 @@ private:
     static constexpr int kAux = 3;            // ResBlock chains of one decoder stage run concurrently
     hipStream_t aux_[kAux] = {};
     hipEvent_t ev_fork_ = nullptr, ev_join_[kAux] = {};
+    hipEvent_t ev_setup_ = nullptr;      // behind run_setup's upload of the pinned staging block (batches)
     hipStream_t cur_ = nullptr;               // stream the conv()/ln() helpers launch on
     bool have_events_ = false;
     int cur_stage_ = 0;

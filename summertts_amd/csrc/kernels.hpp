@@ -300,6 +300,10 @@ void istft_ola(const float* spec, long ld, int bands, int band_rows, SegView seg
 // polyphase synthesis FIR over the x4 zero-stuffed band signals: out[i] = sum_tau sum_b g*tm[b][(i+tau-pad)/4]*fir[tau*4+b]
 void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, int ntap, int pad, float gain, float bias,
                float* wave, int16_t* pcm, SegView seg_out, int B, int max_n, hipStream_t st);
+// istft_spectrum + istft_ola + synth_fir as one launch (4 bands + synthesis filter: the MBB / MS decoders); sb as for istft_spectrum
+bool istft_tail_fused_ok(int bands, int ntap, int pad);
+void istft_tail_fused(const float* sb, long ld, SegView seg_frames, const float* fir, int ntap, int pad, float gain, float bias, float* wave, int16_t* pcm,
+                      SegView seg_out, int B, int max_n, hipStream_t st);
 // pcm = (int16)(int32)(wave * 32737)   (SynthesizerTrn.cpp:389-396: truncation, wrap-around)
 void quantize_pcm(const float* wave, int16_t* pcm, long n, hipStream_t st);
 

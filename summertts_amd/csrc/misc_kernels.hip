@@ -557,7 +557,7 @@ void attention(const AttnArgs& a, hipStream_t st) {
         static const bool no_mfma = exp_flag("STS_NO_ATTN_MFMA");   // experiment knob
         const int Tpad = (a.max_len + 63) / 64 * 64;
         const size_t lds = attention_mfma_lds(a, Tpad);
-        // Measured: the block kernel is one long dependent chain per workgroup -- with 16 workgroups (one
+        // Measured (docs/HISTORY.md 5b): the block kernel is one long dependent chain per workgroup -- with 16 workgroups (one
         // 128-phoneme utterance) it takes 26 us against 11.5 us for the one-query-per-workgroup kernel; from about a
         // hundred workgroups on it wins (batch 8: 98 -> 45 us per launch, text encoder 1.21 -> 0.88 ms)
         const long wgs = (long)((a.max_len + 15) / 16) * a.nheads * a.B;
@@ -682,7 +682,7 @@ void spline_step(const float* h, long ld, float filter_sqrt, const float* r0, co
 // ---------------------------------------------------------------------------------------------
 // durations: w = exp(logw) * lengthScale ; ceil ; (int) ; inclusive scan ; frames = max(sum, 1)
 // (/root/reference/src/models/SynthesizerTrn.cpp:376-378, 304-321; ElementwiseAffine.cpp:44-58)
-constexpr int kMaxDur = 100000;   // sanity clamp per phoneme (the reference has none; see DESIGN.md)
+constexpr int kMaxDur = 100000;   // sanity clamp per phoneme (the reference has none; see DESIGN.md 9)
 __global__ __launch_bounds__(256) void durations_kernel(const float* r0, int sdp, float ea_m, float ea_logs,
                                                         const float* ls, const int* forced, float* logw_out,
                                                         int* dur, int* cum, int* frames, SegView seg,
@@ -879,6 +879,92 @@ void synth_fir(const float* tm, long tm_ld, SegView seg_tm, const float* fir, in
     if (B <= 0 || max_n <= 0) return;
     hipLaunchKernelGGL(synth_fir_kernel, dim3((4 * max_n + 255) / 256, B), dim3(256), 0, st, tm, tm_ld, seg_tm, fir, ntap,
                        pad, gain, bias, wave, pcm, seg_out);
+}
+
+// ---- the three launches above as ONE (round 6; SURVEY.md 7 planned the tail as one kernel): a workgroup owns 1024 output samples of one
+// utterance = 256 time-domain samples per band (+ 8 either side for the synthesis filter) = 71 iSTFT frames.  Phase A: the spectrum of those
+// frames (exp / pi sin / cos, sin) into LDS; phase B: 16-point inverse DFT + Hann + overlap-add + normalisation per band into LDS; phase C: the x4
+// zero-stuffed polyphase synthesis filter (PQMF bank or the MS model's learned filter) + the int16 cast.  The spectrum (72 floats per frame) and the
+// band signals (16 floats per frame) never reach memory: 0.76 -> ~0.3 ms of a 33 ms step at 64 MB-iSTFT utterances, three ~8 us launches -> one at
+// one utterance.  Same expressions in the same order as the three kernels above (which remain for the plain-iSTFT decoder and as the lab A/B).
+// /root/reference/src/models/Generator_MBB.cpp:186-203, modules/iStft.cpp:46-124, modules/pqmf.cpp:104-115
+constexpr int TF_T = 256, TF_HALO = 8, TF_TW = TF_T + 2 * TF_HALO, TF_FR = 72;     // band samples per workgroup, halo, staged width, frames staged (71 used)
+__global__ __launch_bounds__(256) void istft_tail_fused_kernel(const float* sb, long ld, SegView segf, const float* fir, int ntap, int pad, float gain,
+                                                               float bias, float* wave, int16_t* pcm, SegView sego) {
+    __shared__ float spec[4][18][TF_FR];
+    __shared__ float tmv[4][TF_TW];
+    __shared__ float firs[256];
+    const int b = blockIdx.y;
+    const int frames = seg_len(segf, b);
+    const int n = (frames - 1) * 4, N = 4 * n;
+    const int t0 = blockIdx.x * TF_T;
+    if (t0 >= n) return;
+    const size_t fb = (size_t)seg_start(segf, b), ob = (size_t)seg_start(sego, b);
+    const int tid = threadIdx.x;
+    const int fl0 = (t0 >> 2) - 3;                        // first staged frame (t0 is a multiple of 4)
+    if (tid < ntap * 4 && tid < 256) firs[tid] = fir[tid];
+    // ---- A: spectrum of frames [fl0, fl0 + 71)
+    for (int it = tid; it < 4 * 9 * TF_FR; it += 256) {
+        const int fi = it % TF_FR, kk = it / TF_FR;       // kk = band * 9 + k
+        const int band = kk / 9, k = kk - band * 9;
+        const int f = fl0 + fi;
+        if (f >= 0 && f < frames) {
+            const float mag = expf(sb[(size_t)(band * 18 + k) * ld + fb + f]);
+            const float ph = sinf(sb[(size_t)(band * 18 + 9 + k) * ld + fb + f]) * 3.14159265358979323846f;
+            spec[band][k][fi] = cosf(ph) * mag;
+            spec[band][9 + k][fi] = sinf(ph) * mag;
+        }
+    }
+    __syncthreads();
+    // ---- B: band samples [t0 - 8, t0 + 264)
+    for (int it = tid; it < 4 * TF_TW; it += 256) {
+        const int band = it / TF_TW, sl = it - band * TF_TW;
+        const int s = t0 - TF_HALO + sl;
+        float acc = 0.f;
+        if (s >= 0 && s < n) {
+            const int p = s + 8;
+            int f0 = (p - 15 + 3) >> 2; if (f0 < 0) f0 = 0;
+            int f1 = p >> 2; if (f1 > frames - 1) f1 = frames - 1;
+            float ws = 0.f;
+            for (int f = f0; f <= f1; f++) {
+                const int idx = p - 4 * f, fi = f - fl0;
+                float v = spec[band][0][fi] + ((idx & 1) ? -spec[band][8][fi] : spec[band][8][fi]);
+#pragma unroll
+                for (int k = 1; k < 8; k++) {
+                    const int ang = (k * idx) & 15;
+                    v += 2.0f * (spec[band][k][fi] * kCos16[ang] - spec[band][9 + k][fi] * kCos16[(ang + 12) & 15]);
+                }
+                acc += (v * 0.0625f) * kHann[idx];
+                ws += kHannPow[idx];
+            }
+            if (ws > 1e-14f) acc = acc / ws;
+        }
+        tmv[band][sl] = acc;
+    }
+    __syncthreads();
+    // ---- C: output samples [4 t0, 4 t0 + 1024)
+    for (int j = tid; j < 4 * TF_T; j += 256) {
+        const int i = 4 * t0 + j;
+        if (i >= N) break;
+        const int tau0 = ((pad - i) % 4 + 4) % 4;
+        float s = 0.f;
+        for (int tau = tau0; tau < ntap; tau += 4) {
+            const int u = i + tau - pad;
+            if (u < 0 || u >= N) continue;
+            const int tl = (u >> 2) - t0 + TF_HALO;
+#pragma unroll
+            for (int q = 0; q < 4; q++) s += (gain * tmv[q][tl]) * firs[tau * 4 + q];
+        }
+        s += bias;
+        if (wave) wave[ob + i] = s;
+        pcm[ob + i] = pcm_cast(s);
+    }
+}
+bool istft_tail_fused_ok(int bands, int ntap, int pad) { return bands == 4 && ntap * 4 <= 256 && pad <= 4 * TF_HALO - 1 && ntap - 1 - pad <= 4 * TF_HALO - 1; }
+void istft_tail_fused(const float* sb, long ld, SegView seg_frames, const float* fir, int ntap, int pad, float gain, float bias, float* wave, int16_t* pcm,
+                      SegView seg_out, int B, int max_n, hipStream_t st) {
+    if (B <= 0 || max_n <= 0) return;      // max_n = band samples of the longest utterance
+    hipLaunchKernelGGL(istft_tail_fused_kernel, dim3((max_n + TF_T - 1) / TF_T, B), dim3(256), 0, st, sb, ld, seg_frames, fir, ntap, pad, gain, bias, wave, pcm, seg_out);
 }
 
 __global__ void quantize_pcm_kernel(const float* wave, int16_t* pcm, long n) {

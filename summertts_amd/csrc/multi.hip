@@ -381,6 +381,7 @@ int sts_multi_create_ex(const float* blob, int64_t blob_bytes, const int32_t* de
     if (!m) return multi_err(STS_EDEVICE, "out of host memory");
     for (int k = 0; k < n_devices; k++) {
         m->engines.emplace_back(new Engine());
+        m->engines.back()->polite_wait = true;      // worker threads sleep through most of a run's host waits (engine.hpp)
         m->engines.back()->host_pcm = !want_rccl;
         const int rc = m->engines.back()->init(blob, blob_bytes, devices[k]);
         if (rc != STS_OK) { multi_err(rc, "device " + std::to_string(devices[k]) + ": " + m->engines.back()->error()); delete m; return rc; }

@@ -113,6 +113,7 @@ int sts_pool_create(const float* blob, int64_t blob_bytes, int device, int n_eng
     p->max_batch = max_batch;
     for (int k = 0; k < n_engines; k++) {
         p->engines.emplace_back(new Engine());
+        p->engines.back()->polite_wait = true;      // worker threads sleep through most of a run's host waits (engine.hpp)
         p->engines.back()->host_pcm = true;
         const int rc = p->engines.back()->init(blob, blob_bytes, device);
         if (rc != STS_OK) { pool_err(rc, p->engines.back()->error()); delete p; return rc; }

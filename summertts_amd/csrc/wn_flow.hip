@@ -4,9 +4,9 @@
 // ResidualCouplingLayer.cpp:47-66 (h = pre(x0); m = post(WN(h)); x1 -= m), ResidualCouplingBlock.cpp:59-70 (couplings in reverse order).
 //
 // Why.  At one utterance the flow was 40 dependent launches of 9-14 us (pre, 4 x (gate conv, res/skip conv), post per coupling), each a
-// chip-wide launch whose price is the launch itself, on the exact-fp32 MFMA with dword operand loads.  Fusing the gate conv
+// chip-wide launch whose price is the launch itself (docs/HISTORY.md 5b), on the exact-fp32 MFMA with dword operand loads.  Fusing the gate conv
 // with the res/skip conv that consumes it needs a workgroup that owns ALL 2H gate rows of its columns -- 21 workgroups for 668 frames,
-// compute-starved -- unless the 1x1 conv is cut along K instead:
+// compute-starved (docs/HISTORY.md 5b) -- unless the 1x1 conv is cut along K instead:
 //
 //   * the H gated channels are cut into G groups of Cg = 32 (16) channels.  Workgroup (column tile of 32 frames, group g) stages the
 //     layer's whole input window h (all H channels x 32 + 2 halo frames), runs the gate conv for ITS 2 Cg gate rows only (K = H x k),

@@ -36,6 +36,11 @@ def test_gpus_2_spawns_two_ranks_and_gathers():
     assert sum(mg["samples_per_rank"]) == 3 * 100 * sum(lens)               # every rank's samples, all steps
     assert mg["gathered_samples_rank0"] == 3 * 100 * sum(lens)              # ... and all of them arrived on rank 0
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 3 - sum(mg["samples_per_rank"])) < 1.0
+    # round 6: the same invocation also measures the library's native gather (rank 0, in-process, after the distributed run)
+    nat = out["multi_native"]
+    assert "error" not in nat, nat
+    assert nat["n_gpus"] == 2 and nat["rccl_ranks"] == 2 and nat["gather_mode"] == "rccl" and nat["value"] > 0 and nat["gather_ms_per_step"] > 0
+    assert sum(nat["samples_per_device"]) == 3 * 100 * sum(lens)
 
 
 def test_torchrun_style_environment_is_respected():

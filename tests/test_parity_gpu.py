@@ -643,6 +643,71 @@ def test_full_size_configs_match_reference_golden(path, math):
     syn.close()
 
 
+@pytest.mark.parametrize("path", [p for p in golden_files_v2("full_") + golden_files_v2("loud_") + golden_files_v2("real_") if "tiny" not in p],
+                         ids=lambda p: p.split("/")[-1])
+def test_pre_split_trunk_path_matches_reference_golden(path):
+    """Round 6: the decoder stages of 128 k channels on pre-split, channel-minor activations (conv_h2p.hip: entry split, planes / x16
+    epilogues, LDS-DMA staging).  The engine takes that path by itself from ~8 tiles per CU on; here it is FORCED (sts_debug_set h2p = 2) for
+    every full-size fixture the real reference produced -- single utterances (ragged tile edges, one tile per CU) and the 8- / 32- / 64-
+    utterance batches, Gaussian and realistic weight statistics, near-full-scale outputs -- under the same unscaled tolerances, and the
+    staged kernels (h2p = 0) run the same fixture next to it.  /root/reference/src/modules/ResBlock1.cpp:55-69, Generator_hifigan.cpp:151-175."""
+    g, cfg, blob, utts, stride = load_golden_v2(path)
+    syn = engine.Synthesizer(blob)
+    syn.set_conv_math("f16x2")
+    syn.set_record_taps(True)
+    syn.set_profiling(True)
+    for h2p in (2, 0):
+        syn.debug_set("h2p", h2p)
+        if "batch_lens" in g:
+            lens = [int(t) for t in g["batch_lens"]]
+            sids = [int(v) for v in g["batch_sids"]]
+            ids = [sb.synthetic_ids(t, cfg.vocab, salt=u) for u, t in enumerate(lens)]
+            n_out = syn.run_batch(ids, sids, [1.0] * len(ids))
+            assert syn.profile()["conv_math_fallbacks"] == 0
+            pcm = syn.pcm_host()
+            wave = syn.tap("wave")[0]
+            dur = syn.durations(sum(lens))
+            soff = np.concatenate([[0], np.cumsum(n_out)])
+            toff = np.concatenate([[0], np.cumsum(lens)])
+            for u, ids_u, sid_u, ls_u, dur_u, pcm_u, wave_u in utts:
+                assert (dur[toff[u]:toff[u + 1]] == dur_u).all(), f"utterance {u}: durations differ from the reference"
+                assert_pcm_close(pcm[soff[u]:soff[u + 1]], pcm_u, f"{path} utterance {u} of the batch (h2p={h2p})")
+                assert_wave_close(wave[soff[u]:soff[u + 1]][::stride], wave_u, f"{path} utterance {u} of the batch (h2p={h2p})")
+        else:
+            for u, ids_u, sid_u, ls_u, dur_u, pcm_u, wave_u in utts:
+                syn.run_batch([ids_u], [sid_u], [ls_u])
+                assert syn.profile()["conv_math_fallbacks"] == 0
+                assert (syn.durations(len(ids_u)) == dur_u).all(), f"utterance {u}: durations differ from the reference"
+                assert_pcm_close(syn.pcm_host(), pcm_u, f"{path} utterance {u} (h2p={h2p})")
+                assert_wave_close(syn.tap("wave")[0][::stride], wave_u, f"{path} utterance {u} (h2p={h2p})")
+    syn.close()
+
+
+@pytest.mark.parametrize("C,k,dil,L", [(128, 3, 1, 777), (128, 7, 3, 1500), (128, 11, 5, 300), (256, 3, 1, 1029), (256, 11, 5, 97), (128, 3, 1, 5), (512, 3, 1, 130)])
+def test_pre_split_conv_against_float64(C, k, dil, L):
+    """One conv through split_planes + conv_h2p_group, every tile code, all three output forms (fp32 [C][L], the channel-minor fp32 copy, the
+    two fp16 planes of lrelu(out)): as accurate against float64 as the staged two-term kernel (the k order inside a 16-channel chunk differs,
+    so the two are not bit-identical), the channel-minor copy bit-equal to the plain one, the planes within 2^-21 of lrelu(out).
+    /root/reference/src/nn_op/nn_conv1d.cpp:118-199."""
+    rng = np.random.default_rng(C + k + L)
+    x = rng.standard_normal((C, L)).astype(np.float32) * 1.5
+    w = (rng.standard_normal((C, k, C)) / np.sqrt(k * C)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal((C, L)).astype(np.float32)
+    xa = np.where(x < 0, x * np.float32(0.1), x).astype(np.float64)
+    pad = dil * (k - 1) // 2
+    xp = np.pad(xa, ((0, 0), (pad, pad)))
+    r64 = sum(w[:, t, :].astype(np.float64) @ xp[:, t * dil:t * dil + L] for t in range(k)) + b[:, None] + res
+    staged = engine.debug_conv1d(x, w, b, pad, dil, 0, False, 0.1, 1, mode=60) + res
+    e_staged = float(np.abs(staged - r64).max())
+    for tile in range(11):
+        y, y16, yp, _ = engine.debug_conv_h2p(x, w, b, dil, res, 0.1, 0.1, tile=tile, members=2 if tile % 2 else 1)
+        lre = np.where(y < 0, y * np.float32(0.1), y)
+        assert np.abs(y - r64).max() <= 1.5 * e_staged + 1e-7, (tile, float(np.abs(y - r64).max()), e_staged)
+        assert np.array_equal(y16, y), tile
+        assert np.abs(yp - lre).max() <= 5e-7 * max(1.0, float(np.abs(lre).max())), tile
+
+
 @pytest.mark.parametrize("path", golden_files_v2("loud_"), ids=lambda p: p.split("/")[-1])
 def test_near_full_scale_utterances_discriminate_the_trunk_arithmetics(path):
     """the bench-shaped models peak at |o| ~ 0.05 of full scale, where "int16 within 1 LSB" is a ~5e-4-relative

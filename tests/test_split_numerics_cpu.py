@@ -94,7 +94,7 @@ def test_three_products_of_the_scaled_two_term_form_match_an_fp32_chain_at_every
 
 
 def test_winograd_domain_operands_survive_the_two_term_split():
-    """tools/wino_f16x2_numerics.py: the segmented F(2,3) / F(2,2) form of a dilated ResBlock conv -- input transform in
+    """tools/wino_f16x2_numerics.py (docs/HISTORY.md 12): the segmented F(2,3) / F(2,2) form of a dilated ResBlock conv -- input transform in
     fp32, weight transform in float64, then the shipped two-term fp16 split with ONE power-of-two scale per conv -- is at least as
     accurate as the shipped direct two-term form and as an fp32 multiply-add chain, with 4 n3 + 3 n2 instead of 2 k matrix products per
     output pair.  (A statement about the arithmetic only: no such kernel is shipped.)"""

@@ -1,5 +1,5 @@
 """Numerical model (numpy, CPU) of fp32 dot products computed on narrow-operand matrix cores with split operands, against
-float64 -- the study behind conv_bf3.hip and behind the open question whether TWO fp16 terms (3 products,
+float64 -- the study behind conv_bf3.hip (docs/HISTORY.md 5d) and behind the open question whether TWO fp16 terms (3 products,
 half the matrix instructions of the shipped 3 x bf16 / 6 products scheme) could serve.
 
   python tools/split_numerics.py

@@ -1,7 +1,7 @@
 """Numerical model (numpy, CPU) of a dilated k-tap conv layer computed in the WINOGRAD domain on the fp16 matrix cores with two-term
-operands -- the arithmetic question behind the next step for the decoder trunk: the exact-fp32 path already runs its
+operands -- the arithmetic question behind the next step for the decoder trunk (docs/HISTORY.md 12): the exact-fp32 path already runs its
 ResBlock layers as segmented F(2,3) / F(2,2) (resblock_wino_kernel: 0.67-0.73 of the direct form's matrix products), the default
-two-term fp16 path (conv_bf3.hip MATH 1) runs the direct form.  Would the transform-domain operands survive the split?
+two-term fp16 path (conv_bf3.hip MATH 1, docs/HISTORY.md 5f) runs the direct form.  Would the transform-domain operands survive the split?
 
   python tools/wino_f16x2_numerics.py
 
