@@ -161,7 +161,7 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_ATTN_BLOCK_MIN_WGS: if (value < 1) return set_err(STS_EINVAL, "threshold must be >= 1"); e->eng.attn_block_min_wgs = value; return STS_OK;
         case STS_DBG_FLOW_FUSED: e->eng.flow_fused = value != 0; return STS_OK;
         case STS_DBG_LAUNCH_AHEAD: if (value < 0 || value > 2) return set_err(STS_EINVAL, "launch_ahead must be 0, 1 or 2"); if ((value == 2) != (e->eng.launch_ahead == 2)) { e->eng.seen_tf_.clear(); e->eng.seen_order_.clear(); } e->eng.launch_ahead = value; return STS_OK;
-        case STS_DBG_H2P: e->eng.h2p = value < 0 ? 0 : (value > 2 ? 2 : value); return STS_OK;
+        case STS_DBG_H2P: e->eng.h2p = value < 0 ? 0 : (value > 5 ? 5 : value); return STS_OK;
         case STS_DBG_H2P_TILE: e->eng.h2p_tile = value; return STS_OK;
         case STS_DBG_CHAIN_STREAMS: e->eng.chain_streams_dbg = value; return STS_OK;
         case STS_DBG_TAIL_FUSED: e->eng.tail_fused = value != 0; return STS_OK;

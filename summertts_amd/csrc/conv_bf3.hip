@@ -91,7 +91,7 @@ size_t bf3_pack(const float* wp, int nphase, int ntap, int Cin_pad, int Cout_pad
 }
 
 bool conv_bf3_eligible(const ConvArgs& a) {
-    if (!a.wb3 || a.depthwise || a.in_reflect) return false;
+    if (!a.wb3 || a.depthwise || (a.in_reflect && a.transposed)) return false;
     if (a.Cin != a.Cin_pad || a.Cin_pad % CK != 0 || a.Cout_pad % 32 != 0 || a.Cin < 32) return false;
     if ((double)a.x_ld * 64.0 >= 4.0e9) return false;       // 16 rows of a chunk behind one 32-bit buffer descriptor
     const int first = a.tap_off, last = a.tap_off + (a.ntap - 1) * a.tap_step;
@@ -146,7 +146,7 @@ long conv_bf3_blocks(const ConvArgs& a) {
 
 // the tiles instantiated with the summed-input staging: the ones the automatic choice gives a transposed conv (upsamplers)
 bool conv_bf3_takes_sum(const ConvArgs& a) {
-    if (!conv_bf3_eligible(a) || a.nsum < 2 || a.nsum > 3 || !a.xs1 || (a.nsum == 3 && !a.xs2)) return false;
+    if (!conv_bf3_eligible(a) || a.in_reflect || a.nsum < 2 || a.nsum > 3 || !a.xs1 || (a.nsum == 3 && !a.xs2)) return false;
     const int nphase = a.transposed ? a.out_stride : 1;
     const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
     // every workgroup that stages a window forms the mean itself (3 reads + a division per staged value), so the fold only pays where a

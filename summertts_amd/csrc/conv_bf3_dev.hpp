@@ -244,7 +244,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     long long* tt_rec = tt_open(0, tt_member);     // kind 0 = staged conv (stamps: start, first barrier, K loop done, epilogue done)
     TT_STAMP(0);
 #endif
-    const int in_len = uni(seg_len(a.in_seg, b));
+    // (in_reflect, MB-iSTFT subband conv: the logical input is the reflect-pad-left-1 view of x -- position p reads x[p - 1], p = 0 reads x[1])
+    const int orig_len = uni(seg_len(a.in_seg, b));
+    const int in_len = orig_len + (a.in_reflect ? 1 : 0);
     const int out_len = uni(seg_len(a.out_seg, b));
     const int n_count = a.transposed ? in_len + a.n_extra : out_len;
     const int n0 = bx * NT;
@@ -326,8 +328,10 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         const int pos = win0 + col;
         isub[i] = sub;
         sact[i] = it < NITEM && slot * 32 < W;
-        const bool v = col < W && pos >= 0 && pos < in_len;
-        xoff[i] = v ? (unsigned)half * 8u * ld4 + (unsigned)pos * 4u : kOOB;
+        bool v = col < W && pos >= 0 && pos < in_len;
+        int src = pos;
+        if (a.in_reflect) { src = pos - 1; if (src < 0) { src = 1; v = v && orig_len > 1; } }
+        xoff[i] = v ? (unsigned)half * 8u * ld4 + (unsigned)src * 4u : kOOB;
         lds_w[i] = sub * SUB + col * 32 + ((half ^ ((col >> 3) & 1)) << 4);
     }
     float xr[SPW][8];
@@ -348,7 +352,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
         for (int i = 0; i < SPW; i++)
             if (sact[i]) {
                 const size_t row0 = (size_t)(c * NSUB + isub[i]) * CK * x_ld + in_base;
-                const unsigned span = (unsigned)((15ul * x_ld + in_len) * 4ul);
+                const unsigned span = (unsigned)((15ul * x_ld + orig_len) * 4ul);
                 const rsrc_t rs = make_rsrc(xbase + row0, span);
 #pragma unroll
                 for (int e = 0; e < 8; e++)

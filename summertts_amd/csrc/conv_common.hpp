@@ -259,6 +259,52 @@ __device__ __forceinline__ void tile_epilogue_impl(const ConvArgs& a, f32x16 (&a
         });
         return;
     }
+    if (a.epi == EPI_GATE && a.out_stride == 1) {
+        // Round 6: the WaveNet gate with 16-byte stores.  Registers r and r + 8 of a lane are tile rows (c, c + 16) = the tanh and the sigmoid
+        // pre-activation of gated channel 16 (tile) + c; the lane's 8 gated values are channels {4 half + 0..3} and {8 + 4 half + 0..3} of ONE
+        // column -- two groups of 4 consecutive channels, which the in-quad transpose turns into 4 consecutive columns of one channel each
+        // (conv_common.hpp quad_transpose, as the plain epilogue above).  Same arithmetic per value as the scalar form below.
+        const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (mbase + i * 32 < a.Cout_pad) {
+                float bt[8], bs[8], ut[8], us[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int rowp = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    bt[r] = a.bias ? a.bias[rowp] : 0.f;
+                    bs[r] = a.bias ? a.bias[rowp + 16] : 0.f;
+                    ut[r] = a.ubias ? a.ubias[(size_t)rowp * a.ubias_ld + b] : 0.f;
+                    us[r] = a.ubias ? a.ubias[(size_t)(rowp + 16) * a.ubias_ld + b] : 0.f;
+                }
+                static_for<0, NW>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    float gv[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                        gv[r] = tanh_ref(a.ubias ? (acc[i][q][r] + bt[r]) + ut[r] : acc[i][q][r] + bt[r]) *
+                                sigmoid_ref(a.ubias ? (acc[i][q][r + 8] + bs[r]) + us[r] : acc[i][q][r + 8] + bs[r]);
+                    const int n = ncol0 + q * 32 + m4;
+                    const int pos = n + out_off;
+                    const bool full = n + 3 < n_count && pos >= 0 && pos + 3 < out_len;
+                    const bool any = n < n_count && pos + 3 >= 0 && pos < out_len;
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        float w[4] = {gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]};
+                        quad_transpose(w, l31);
+                        const int rowp = mbase + i * 32 + 8 * g + 4 * half + lane4;        // tile row of the tanh half
+                        const int ch = (rowp >> 5) * 16 + (rowp & 15);
+                        if (ch < a.H && any) {
+                            float* yp = a.y + (size_t)ch * a.y_ld + out_base + pos;
+                            if (full) *(f32x4u*)yp = f32x4u{w[0], w[1], w[2], w[3]};
+                            else { for (int e = 0; e < 4; e++) if (n + e < n_count && pos + e >= 0 && pos + e < out_len) yp[e] = w[e]; }
+                        }
+                    }
+                });
+            }
+        });
+        return;
+    }
     if (a.epi == EPI_GATE) {
         // rows r and r + 8 of a lane's 16 accumulator rows are tile rows (c, c + 16): the tanh and the sigmoid pre-activation of one
         // channel (model.hip gate_perm_row); a row tile's 16 bias values are requested together
@@ -286,6 +332,65 @@ __device__ __forceinline__ void tile_epilogue_impl(const ConvArgs& a, f32x16 (&a
                             const int ch = (rowp >> 5) * 16 + (rowp & 15);
                             if (ch < a.H) a.y[(size_t)ch * a.y_ld + opos] = tanh_ref(a.ubias ? (acc[i][q][r] + bt[r]) + ut[r] : acc[i][q][r] + bt[r]) *
                                                                             sigmoid_ref(a.ubias ? (acc[i][q][r + 8] + bs[r]) + us[r] : acc[i][q][r + 8] + bs[r]);
+                        }
+                    }
+                });
+            }
+        });
+        return;
+    }
+    if ((a.epi == EPI_RESSKIP || a.epi == EPI_SUB) && a.out_stride == 1) {
+        // Round 6: the flow's read-modify-write epilogues (WN res / skip split, coupling "x1 -= m") through 16-byte accesses: after the in-quad
+        // transpose a lane holds 4 consecutive columns of one row, so the old values arrive in one 16-byte load per 4 registers and leave in one
+        // store (the scalar form below: 16 dword loads + 16 dword stores per accumulator tile and lane -- these launches were epilogue-bound:
+        // the res/skip conv has 12 K steps).  Which tensor a row belongs to (h / skip, x1) is a property of the row: uniform per store.
+        const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (mbase + i * 32 < a.Cout_pad) {
+                float bv[4], uv[4];
+                float* rowptr[4]; bool ld_old[4], rok[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int rowp = mbase + i * 32 + 8 * g + 4 * half + lane4;
+                    bv[g] = a.bias ? a.bias[rowp] : 0.f;
+                    uv[g] = (a.ubias && rowp < a.Cout) ? a.ubias[(size_t)rowp * a.ubias_ld + b] : 0.f;
+                    rok[g] = rowp < a.Cout;
+                    ld_old[g] = true;
+                    if (a.epi == EPI_SUB || (a.Cout != a.H && rowp < a.H)) rowptr[g] = a.y + (size_t)rowp * a.y_ld;
+                    else { rowptr[g] = a.aux + (size_t)(a.Cout != a.H ? rowp - a.H : rowp) * a.aux_ld; ld_old[g] = !(a.epi_flag & 1); }
+                }
+                static_for<0, NW>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const int n = ncol0 + q * 32 + m4;
+                    const int pos = n + out_off;
+                    const bool full = n + 3 < n_count && pos >= 0 && pos + 3 < out_len;
+                    const bool any = n < n_count && pos + 3 >= 0 && pos < out_len;
+                    auto ok = [&](int e) { return n + e < n_count && pos + e >= 0 && pos + e < out_len; };
+                    f32x4u old[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        old[g] = f32x4u{0.f, 0.f, 0.f, 0.f};
+                        if (rok[g] && ld_old[g] && any) {
+                            const float* rp = rowptr[g] + out_base + pos;
+                            if (full) old[g] = *(const f32x4u*)rp;
+                            else { for (int e = 0; e < 4; e++) if (ok(e)) old[g][e] = rp[e]; }
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        float w[4] = {acc[i][q][4 * g], acc[i][q][4 * g + 1], acc[i][q][4 * g + 2], acc[i][q][4 * g + 3]};
+                        quad_transpose(w, l31);
+                        if (rok[g] && any) {
+                            f32x4u o;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float v = a.ubias ? (w[e] + bv[g]) + uv[g] : w[e] + bv[g];
+                                o[e] = a.epi == EPI_SUB ? old[g][e] - v : old[g][e] + v;
+                            }
+                            float* wp = rowptr[g] + out_base + pos;
+                            if (full) *(f32x4u*)wp = o;
+                            else { for (int e = 0; e < 4; e++) if (ok(e)) wp[e] = o[e]; }
                         }
                     }
                 });

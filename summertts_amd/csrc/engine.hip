@@ -1092,7 +1092,9 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             // (the entry split is a launch of its own, the second conv of a layer writes two tensors, and a grid of one tile per CU gains nothing
             // from a faster K loop): taken from ~8 tiles of 128 x 128 per CU on.  h2p == 2 (lab): always.
             const long h2p_tiles = (long)((l2.max_len + 127) / 128) * (up.Cout / 128) * l2.nb * nk;
-            bool h2p_stage = conv_math == 3 && h2p && (h2p == 2 || h2p_tiles >= 2048) && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9;
+            bool h2p_stage = conv_math == 3 && h2p && (h2p >= 2 || h2p_tiles >= 2048) && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9;
+            if (h2p == 3 && up.Cout != 128) h2p_stage = h2p_stage && h2p_tiles >= 2048;      // lab: 3 = always for the 128-channel stage only, 4 = always for the wider ones only
+            if (h2p == 4 && up.Cout == 128) h2p_stage = h2p_stage && h2p_tiles >= 2048;
             for (int j = 0; j < nk && h2p_stage; j++) {
                 const DResBlock& rb = M.rb[(size_t)i * nk + j];
                 for (int d = 0; d < nd0 && h2p_stage; d++) {
@@ -1136,6 +1138,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                 }
                 // the 128-channel variant runs 8-wave workgroups, two per CU: only worth it when the grid fills the chip twice
                 if (fuse && R.C > 64) fuse = (long)((l2.max_len + 117) / 118) * l2.nb * nk >= 512;
+                if (fuse && R.C > 64 && h2p == 5 && h2p_stage) fuse = false;      // lab: the pre-split pair instead of the fused 128-channel layer kernel
                 if (fuse && resblock_layer_eligible(R)) {
                     double fl = 0, flw = 0, f = 0;
                     auto wino_ratio = [](int k) { int n3, n2; wino_split(k, &n3, &n2); return (4.0 * n3 + 3.0 * n2) / (2.0 * k); };

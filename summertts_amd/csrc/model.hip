@@ -520,7 +520,9 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c1[i]) || !pack_wino(st, h, rb.c1[i]) || !pack_bf3(st, rb.c1[i]) || !pack_h2p(st, rb.c1[i])) FAIL("resblock convs1"); }
         for (int i = 0; i < n; i++) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), rb.c2[i]) || !pack_wino(st, h, rb.c2[i]) || !pack_bf3(st, rb.c2[i]) || !pack_bf3(st, rb.c2[i], true) || !pack_h2p(st, rb.c2[i])) FAIL("resblock convs2"); }
     }
-    { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_post)) FAIL("conv_post"); }
+    { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.conv_post)) FAIL("conv_post");
+      // the MB-iSTFT / iSTFT heads (128 -> 72 / 18 channels, 7 taps) run on the split-operand kernels at batch (round 6); HiFi-GAN's one-channel output conv has its own FIR kernel
+      if (m.dec_type != 0 && !pack_bf3(st, m.conv_post)) FAIL("conv_post pack"); }
     if (m.dec_type == 0 && m.is_ms == 1) { HConv h = parse_conv(r); if (!r.ok || !pack_conv(st, h, PackOpts(), m.dec_cond)) FAIL("decoder cond"); }
     if (m.dec_type == 0) { if (m.conv_post.Cout != 1) FAIL("conv_post must have one output channel"); }
     else if (m.dec_type == 2) { if (m.conv_post.Cout != 18) FAIL("iSTFT head must emit 18 channels (iStft(16,4,16) is hard-coded)"); m.hop_total *= 4; }

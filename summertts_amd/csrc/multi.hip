@@ -115,16 +115,40 @@ struct sts_multi {
     // communicator when the call returns.  So no thread ever passes an aborted (freed) or null communicator into RCCL.
     std::vector<int> in_call; std::vector<char> abort_pending;
     int gather_arrived = 0; int64_t gather_epoch = 0;       // host barrier in front of the gather (the collective timeout must not cover the peers' inference)
+    static constexpr int kAbortGraceMs = 2000;
     void abort_all() {
-        std::lock_guard<std::mutex> lk(mu);
-        if (rccl_broken) return;
-        rccl_broken = true;
-        Rccl& R = rccl();
-        for (size_t k = 0; k < comms.size(); k++) {
-            if (!comms[k]) continue;
-            if (in_call[k] > 0) { abort_pending[k] = 1; continue; }
-            if (R.CommAbort) (void)R.CommAbort(comms[k]);
-            comms[k] = nullptr;       // (without ncclCommAbort in the library the communicator is simply abandoned)
+        bool pending = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rccl_broken) return;
+            rccl_broken = true;
+            Rccl& R = rccl();
+            for (size_t k = 0; k < comms.size(); k++) {
+                if (!comms[k]) continue;
+                if (in_call[k] > 0) { abort_pending[k] = 1; pending = true; continue; }
+                if (R.CommAbort) (void)R.CommAbort(comms[k]);
+                comms[k] = nullptr;       // (without ncclCommAbort in the library the communicator is simply abandoned)
+            }
+        }
+        if (!pending) return;
+        // Watchdog: an owner inside an RCCL host call normally returns at once (the peers' communicators are gone) and aborts its
+        // own.  A host call that BLOCKS on the failed peer (lazy connection set-up inside the first ncclAllGather, ncclGroupEnd) never returns by
+        // itself: after a grace period the aborting thread calls ncclCommAbort on it from here -- RCCL's documented way to unblock a stuck call.
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                bool any = false;
+                for (size_t k = 0; k < comms.size(); k++) any = any || (abort_pending[k] && comms[k]);
+                if (!any) return;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(kAbortGraceMs)) {
+                    Rccl& R = rccl();
+                    for (size_t k = 0; k < comms.size(); k++)
+                        if (abort_pending[k] && comms[k]) { if (R.CommAbort) (void)R.CommAbort(comms[k]); comms[k] = nullptr; abort_pending[k] = 0; }
+                    return;
+                }
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
     }
     bool broken() { std::lock_guard<std::mutex> lk(mu); return rccl_broken; }
