@@ -206,6 +206,11 @@ int sts_debug_conv_h2p(int device, const float* x, int32_t Cin, int32_t L, const
                        int32_t dil, const float* res, float in_slope, float out_slope, int tile, int members, float* y, float* y16,
                        float* yp, int32_t iters, float* ms_out);
 
+/* The same conv through the Winograd-domain lab kernel (conv_h2w.hip: segmented F(2,3) / F(2,2) on two-term fp16 operands): y = fp32 [C][L],
+ * y16 = its channel-minor output of lrelu(out, out_slope) decoded to [C][L].  C % 128 == 0, odd k >= 3, (k - 1) dil <= 64. */
+int sts_debug_conv_h2w(int device, const float* x, int32_t C, int32_t L, const float* w, const float* bias, int32_t k, int32_t dil, const float* res,
+                       float in_slope, float out_slope, int members, float* y, float* y16, int32_t iters, float* ms_out);
+
 void sts_free(void* p);
 const char* sts_last_error(void);
 

@@ -430,4 +430,80 @@ int sts_debug_conv_h2p(int device, const float* x, int32_t Cin, int32_t L, const
     return rc;
 }
 
+// One "same"-padded conv through the Winograd-domain lab path (conv_h2w.hip): x fp32 [C][L] -> to_x16 -> conv_h2w_group (`members` identical
+// members) -> member 0's fp32 [C][L] output and its x16 output (lrelu(out, out_slope)) decoded to fp32 [C][L].
+int sts_debug_conv_h2w(int device, const float* x, int32_t C, int32_t L, const float* w, const float* bias, int32_t k, int32_t dil, const float* res,
+                       float in_slope, float out_slope, int members, float* y_out, float* y16_out, int32_t iters, float* ms_out) {
+    if (!x || !w || C <= 0 || L <= 0 || k <= 0 || !(k & 1) || dil < 1 || members < 1 || members > kMaxGroup || C % 128) return set_err(STS_EINVAL, "bad conv arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return set_err(STS_EDEVICE, "no HIP device visible (no CPU fallback)");
+    if (hipSetDevice(device) != hipSuccess) return set_err(STS_EDEVICE, "hipSetDevice failed");
+    std::vector<float> wp((size_t)k * C * C, 0.f);
+    for (int o = 0; o < C; o++) for (int t = 0; t < k; t++) for (int ci = 0; ci < C; ci++) wp[((size_t)t * C + ci) * C + o] = w[((size_t)o * k + t) * C + ci];
+    int n3, n2; wino_split(k, &n3, &n2);
+    const int ntapw = 4 * n3 + 3 * n2;
+    std::vector<float> wu((size_t)ntapw * C * C);
+    h2w_transform_weights(wp.data(), k, C, C, wu.data());
+    std::vector<unsigned char> wb(bf3_pack(wu.data(), 1, ntapw, C, C, nullptr, true, 1));
+    float wscale = 1.0f;
+    bf3_pack(wu.data(), 1, ntapw, C, C, wb.data(), true, 1, &wscale);
+    const size_t tb = (size_t)C * L * 4;
+    float *dx = nullptr, *dx16 = nullptr, *db = nullptr, *dres = nullptr, *dres16 = nullptr; void* dwb = nullptr; unsigned* dovf = nullptr;
+    float* dy[kMaxGroup] = {}; float* dy16[kMaxGroup] = {};
+    bool ok = hipMalloc((void**)&dx, tb) == hipSuccess && hipMalloc((void**)&dx16, tb) == hipSuccess && hipMalloc(&dwb, wb.size() + 8192) == hipSuccess &&
+              hipMalloc((void**)&db, (size_t)C * 4) == hipSuccess && hipMalloc((void**)&dovf, 64) == hipSuccess;
+    if (ok && res) ok = hipMalloc((void**)&dres, tb) == hipSuccess && hipMalloc((void**)&dres16, tb) == hipSuccess;
+    for (int m = 0; m < members && ok; m++) ok = hipMalloc((void**)&dy[m], tb) == hipSuccess && hipMalloc((void**)&dy16[m], tb) == hipSuccess;
+    int rc = ok ? STS_OK : set_err(STS_EDEVICE, "hipMalloc failed");
+    if (rc == STS_OK) {
+        (void)hipMemcpy(dx, x, tb, hipMemcpyHostToDevice);
+        (void)hipMemset(dwb, 0, wb.size() + 8192);
+        (void)hipMemcpy(dwb, wb.data(), wb.size(), hipMemcpyHostToDevice);
+        (void)hipMemset(db, 0, (size_t)C * 4);
+        if (bias) (void)hipMemcpy(db, bias, (size_t)C * 4, hipMemcpyHostToDevice);
+        (void)hipMemset(dovf, 0, 64);
+        to_x16(dx, L, C, L, dx16, L, nullptr);
+        if (res) { (void)hipMemcpy(dres, res, tb, hipMemcpyHostToDevice); to_x16(dres, L, C, L, dres16, L, nullptr); }
+        H2WGroup G;
+        memset(&G, 0, sizeof(G));
+        G.n = members; G.seg = SegView{nullptr, nullptr, 1, 0, 0, L}; G.B = 1; G.max_n = L; G.ovf = dovf;
+        for (int m = 0; m < members; m++) {
+            H2WArgs& a = G.g[m];
+            a.x16 = dx16; a.x_ld = L; a.wu = dwb; a.wscale = wscale; a.bias = bias ? db : nullptr; a.res16 = dres16; a.res_ld = L;
+            a.y16 = dy16[m]; a.y16_ld = L; a.y = dy[m]; a.y_ld = L; a.in_slope = in_slope; a.out_slope = out_slope; a.C = C; a.k = k; a.dil = dil;
+        }
+        if (!conv_h2w_group_eligible(G)) rc = set_err(STS_EINVAL, "shape not eligible for the Winograd-domain kernel");
+        else {
+            conv_h2w_group(G, nullptr);
+            if (iters > 0 && ms_out) {
+                hipEvent_t e0, e1;
+                (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                (void)hipDeviceSynchronize();
+                (void)hipEventRecord(e0, nullptr);
+                for (int it = 0; it < iters; it++) conv_h2w_group(G, nullptr);
+                (void)hipEventRecord(e1, nullptr);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                *ms_out = ms / (float)iters;
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            }
+            if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = set_err(STS_EDEVICE, "conv kernel failed");
+        }
+        if (rc == STS_OK) {
+            if (y_out) (void)hipMemcpy(y_out, dy[0], tb, hipMemcpyDeviceToHost);
+            if (y16_out) {
+                std::vector<float> t16((size_t)C * L);
+                (void)hipMemcpy(t16.data(), dy16[0], tb, hipMemcpyDeviceToHost);
+                for (int c = 0; c < C / 16; c++) for (long t = 0; t < L; t++) for (int h = 0; h < 2; h++) for (int e = 0; e < 8; e++)
+                    y16_out[(size_t)(16 * c + 8 * (e >> 2) + 4 * h + (e & 3)) * L + t] = t16[((size_t)c * L + t) * 16 + h * 8 + e];
+            }
+        }
+    }
+    (void)hipFree(dx); (void)hipFree(dx16); (void)hipFree(dwb); (void)hipFree(db); (void)hipFree(dovf);
+    if (dres) (void)hipFree(dres); if (dres16) (void)hipFree(dres16);
+    for (int m = 0; m < kMaxGroup; m++) { if (dy[m]) (void)hipFree(dy[m]); if (dy16[m]) (void)hipFree(dy16[m]); }
+    return rc;
+}
+
 }  // extern "C"

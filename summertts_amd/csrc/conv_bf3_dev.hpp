@@ -210,8 +210,11 @@ __device__ __forceinline__ void step_mfmas(f32x16 (&acc)[MW][NW], const u32x4 (&
         u32x4 p2[MW];                               // P2 = P0 * 2^-11
 #pragma unroll
         for (int i = 0; i < MW; i++) p2[i] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, ac[i][0]) * (_Float16)0.00048828125f);
+#ifndef STS_H2_PRODUCTS_FROM
+#define STS_H2_PRODUCTS_FROM 0      // lab (WRONG results): 1 = only two of the three products -- what would a third fewer MFMAs buy? (the Winograd question)
+#endif
 #pragma unroll
-        for (int p = 0; p < 3; p++)
+        for (int p = STS_H2_PRODUCTS_FROM; p < 3; p++)
 #pragma unroll
             for (int i = 0; i < MW; i++)
 #pragma unroll

@@ -1088,13 +1088,17 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             }
             static const bool no_fuse = exp_flag("STS_NO_FUSE");   // experiment knob
             // the pre-split path (conv_h2p.hip) takes a stage only whole: between its layers the chains' tensors live in the x16 layout
-            // Measured (profiles/r06_h2p_engine_ab.log): -1.4 % of the step at 32 HiFi-GAN utterances, -3.0 % at 64 MB-iSTFT ones, +6 % at ONE utterance
-            // (the entry split is a launch of its own, the second conv of a layer writes two tensors, and a grid of one tile per CU gains nothing
-            // from a faster K loop): taken from ~8 tiles of 128 x 128 per CU on.  h2p == 2 (lab): always.
+            // Measured (profiles/r06_h2p_thresholds_and_two_products.log, r06_h2p_vs_fused128_ab.log).  128 channels: the pre-split pair beats BOTH the
+            // staged grouped pair (one HiFi-GAN utterance, 1 002 tiles of 128 x 128: -1.4 % of the trunk) and the fused 128-channel layer kernel
+            // (2 ... 64 utterances: -4.6 ... -11 % of the trunk although the fused kernel keeps the intermediate on chip -- its whole-window staging and
+            // one-workgroup-per-CU residency cost more than the 8 bytes per value it saves); below ~3 tiles per CU (one MB-iSTFT utterance: 294) the
+            // entry split and the second conv's two output tensors cost more than the faster K loop returns.  256+ channels: from ~2 tiles per CU on
+            // (one HiFi-GAN utterance = 252 tiles needs the K split over two wave groups the staged kernel has).  h2p (lab): 2 = always, 3 / 4 = always for
+            // the 128-channel / the wider stages only, 5 = as 1.
             const long h2p_tiles = (long)((l2.max_len + 127) / 128) * (up.Cout / 128) * l2.nb * nk;
-            bool h2p_stage = conv_math == 3 && h2p && (h2p >= 2 || h2p_tiles >= 2048) && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9;
-            if (h2p == 3 && up.Cout != 128) h2p_stage = h2p_stage && h2p_tiles >= 2048;      // lab: 3 = always for the 128-channel stage only, 4 = always for the wider ones only
-            if (h2p == 4 && up.Cout == 128) h2p_stage = h2p_stage && h2p_tiles >= 2048;
+            const long h2p_min = up.Cout == 128 ? 768 : 512;
+            bool h2p_stage = conv_math == 3 && h2p && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9 &&
+                             (h2p == 2 || (h2p == 3 && up.Cout == 128) || (h2p == 4 && up.Cout != 128) || h2p_tiles >= h2p_min);
             for (int j = 0; j < nk && h2p_stage; j++) {
                 const DResBlock& rb = M.rb[(size_t)i * nk + j];
                 for (int d = 0; d < nd0 && h2p_stage; d++) {
@@ -1138,7 +1142,7 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
                 }
                 // the 128-channel variant runs 8-wave workgroups, two per CU: only worth it when the grid fills the chip twice
                 if (fuse && R.C > 64) fuse = (long)((l2.max_len + 117) / 118) * l2.nb * nk >= 512;
-                if (fuse && R.C > 64 && h2p == 5 && h2p_stage) fuse = false;      // lab: the pre-split pair instead of the fused 128-channel layer kernel
+                if (fuse && R.C > 64 && h2p_stage) fuse = false;       // (round 6: the pre-split pair instead of the fused 128-channel layer kernel)
                 if (fuse && resblock_layer_eligible(R)) {
                     double fl = 0, flw = 0, f = 0;
                     auto wino_ratio = [](int k) { int n3, n2; wino_split(k, &n3, &n2); return (4.0 * n3 + 3.0 * n2) / (2.0 * k); };

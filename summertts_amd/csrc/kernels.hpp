@@ -261,6 +261,23 @@ struct H2PArgs {
 struct H2PGroup { H2PArgs g[kMaxGroup]; int n; SegView seg; int B, max_n; unsigned* ovf; };   // g must stay the first member
 bool conv_h2p_group_eligible(const H2PGroup& G);
 void conv_h2p_group(const H2PGroup& G, hipStream_t st, int tile = -1);
+// ---- the same stages in the Winograd domain (conv_h2w.hip, round 6 lab): segmented F(2,3) / F(2,2), two-term fp16 MFMAs on transformed operands,
+// activations as x16 only (raw fp32, channel-minor); the input transform + split happen in registers from an LDS copy of the raw window
+struct H2WArgs {
+    const float* x16; long x_ld;          // input (C channels); lrelu(in_slope) applied by the kernel (1 = none)
+    const void* wu; float wscale;         // bf3_pack(perm_k, math 1) of the h2w_transform_weights pseudo-taps and the inverse of their scale
+    const float* bias;
+    const float* res16; long res_ld;      // residual (x16) or null
+    float* y16; long y16_ld;              // x16 output of lrelu(out, out_slope) (1 = raw) or null
+    float* y; long y_ld;                  // fp32 [C][y_ld] output or null
+    float in_slope, out_slope;
+    int C, k, dil;                        // Cin = Cout = C, "same" padding dil (k - 1) / 2
+};
+struct H2WGroup { H2WArgs g[kMaxGroup]; int n; SegView seg; int B, max_n; unsigned* ovf; };   // g first (kernarg indexing); members share the dilation
+bool conv_h2w_group_eligible(const H2WGroup& G);
+void conv_h2w_group(const H2WGroup& G, hipStream_t st);
+int h2w_transform_weights(const float* wp, int k, int Cin, int Cout, float* dst);        // wp [k][Cin][Cout] -> dst [4 n3 + 3 n2][Cin][Cout]
+void to_x16(const float* x, long x_ld, int C, long n, float* x16, long out_ld, hipStream_t st);
 // fp32 [C][ld] -> planes of lrelu(x, slope) (+ the x16 copy when x16 != null); n = positions to convert (the packed total)
 void split_planes(const float* x, long x_ld, int C, long n, float slope, void* planes, float* x16, long out_ld, unsigned* ovf, hipStream_t st);
 void conv_generic(const ConvArgs& a, hipStream_t st);

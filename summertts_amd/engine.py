@@ -114,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "sts_create", "sts_destroy", "sts_speaker_num", "sts_get_info", "sts_infer_ids", "sts_infer_ids_batch",
     "sts_run_batch", "sts_copy_pcm_device", "sts_copy_pcm_host", "sts_pcm_host_view", "sts_set_forced_durations",
     "sts_set_record_taps", "sts_get_tap", "sts_get_durations", "sts_set_conv_mode", "sts_set_conv_math", "sts_set_profiling",
-    "sts_get_profile", "sts_set_host_pcm", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_debug_conv_h2p", "sts_free", "sts_last_error",
+    "sts_get_profile", "sts_set_host_pcm", "sts_debug_conv1d", "sts_debug_conv1d_bench", "sts_debug_conv_h2p", "sts_debug_conv_h2w", "sts_free", "sts_last_error",
     "sts_infer_ids_stream", "sts_stream_halo_frames", "sts_debug_wino_pack", "sts_debug_set", "sts_multi_create_ex", "sts_multi_gather_mode", "sts_multi_gather_layout",
     "sts_pool_create", "sts_pool_destroy", "sts_pool_submit", "sts_pool_wait", "sts_pool_stats", "sts_pool_last_error",
     "sts_multi_create", "sts_multi_destroy", "sts_multi_device_count", "sts_multi_speaker_num", "sts_multi_infer_ids_batch",
@@ -336,6 +336,25 @@ def debug_conv_h2p(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], dil
                                        None if r is None else r.ctypes.data, in_slope, out_slope, tile, members, y.ctypes.data,
                                        y16.ctypes.data, yp.ctypes.data, iters, C.byref(ms)))
     return y, y16, yp, float(ms.value)
+
+
+def debug_conv_h2w(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], dil: int = 1, res: Optional[np.ndarray] = None,
+                   in_slope: float = 0.1, out_slope: float = 1.0, members: int = 1, device: int = 0, iters: int = 0):
+    """One 'same'-padded conv through the Winograd-domain lab kernel (conv_h2w.hip).  x: [C, L]; w: [C, k, C].  Returns (y, y16, ms)."""
+    lib = load_library()
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    c, k = w.shape[0], w.shape[1]
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    r = None if res is None else np.ascontiguousarray(res, np.float32)
+    L = x.shape[1]
+    y = np.zeros((c, L), np.float32); y16 = np.zeros((c, L), np.float32)
+    ms = C.c_float(0.0)
+    lib.sts_debug_conv_h2w.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
+    _check(lib, lib.sts_debug_conv_h2w(device, x.ctypes.data, c, L, w.ctypes.data, None if b is None else b.ctypes.data, k, dil,
+                                       None if r is None else r.ctypes.data, in_slope, out_slope, members, y.ctypes.data, y16.ctypes.data, iters, C.byref(ms)))
+    return y, y16, float(ms.value)
 
 
 def debug_wino_pack(w: np.ndarray) -> np.ndarray:

@@ -708,6 +708,29 @@ def test_pre_split_conv_against_float64(C, k, dil, L):
         assert np.abs(yp - lre).max() <= 5e-7 * max(1.0, float(np.abs(lre).max())), tile
 
 
+@pytest.mark.parametrize("C,k,dil,L", [(128, 3, 1, 777), (128, 3, 5, 333), (128, 5, 2, 211), (128, 7, 3, 1500), (128, 11, 5, 300), (256, 11, 1, 190), (256, 7, 5, 131), (128, 3, 1, 5)])
+def test_winograd_domain_lab_conv_against_float64(C, k, dil, L):
+    """conv_h2w.hip (round 6, lab: not dispatched by the engine -- it measures 0.82-0.84 x the direct pre-split kernel's speed):
+    segmented F(2,3) / F(2,2) with two-term fp16 MFMAs on the transformed operands, every tap count it is instantiated for, dilations 1-5, with
+    the residual.  Its error against float64 must not exceed the direct pre-split kernel's (tools/wino_f16x2_numerics.py predicts it is lower),
+    and its channel-minor output of lrelu(out) must equal lrelu of its fp32 output.  /root/reference/src/nn_op/nn_conv1d.cpp:118-199."""
+    rng = np.random.default_rng(C + k + L + dil)
+    x = rng.standard_normal((C, L)).astype(np.float32) * 1.5
+    w = (rng.standard_normal((C, k, C)) / np.sqrt(k * C)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal((C, L)).astype(np.float32)
+    xa = np.where(x < 0, x * np.float32(0.1), x).astype(np.float64)
+    pad = dil * (k - 1) // 2
+    xp = np.pad(xa, ((0, 0), (pad, pad)))
+    r64 = sum(w[:, t, :].astype(np.float64) @ xp[:, t * dil:t * dil + L] for t in range(k)) + b[:, None] + res
+    yd, *_ = engine.debug_conv_h2p(x, w, b, dil, res, 0.1, 0.1, tile=0)
+    y, y16, _ = engine.debug_conv_h2w(x, w, b, dil, res, 0.1, 0.1, members=2)
+    e_dir = float(np.sqrt(((yd - r64) ** 2).mean())); e_w = float(np.sqrt(((y - r64) ** 2).mean()))
+    assert e_w <= 1.05 * e_dir + 1e-8, (e_w, e_dir)
+    assert np.abs(y - r64).max() <= 1.5 * np.abs(yd - r64).max() + 1e-7
+    assert np.array_equal(y16, np.where(y < 0, y * np.float32(0.1), y))
+
+
 @pytest.mark.parametrize("path", golden_files_v2("loud_"), ids=lambda p: p.split("/")[-1])
 def test_near_full_scale_utterances_discriminate_the_trunk_arithmetics(path):
     """the bench-shaped models peak at |o| ~ 0.05 of full scale, where "int16 within 1 LSB" is a ~5e-4-relative
