@@ -161,7 +161,7 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_ATTN_BLOCK_MIN_WGS: if (value < 1) return set_err(STS_EINVAL, "threshold must be >= 1"); e->eng.attn_block_min_wgs = value; return STS_OK;
         case STS_DBG_FLOW_FUSED: e->eng.flow_fused = value != 0; return STS_OK;
         case STS_DBG_LAUNCH_AHEAD: if (value < 0 || value > 2) return set_err(STS_EINVAL, "launch_ahead must be 0, 1 or 2"); if ((value == 2) != (e->eng.launch_ahead == 2)) { e->eng.seen_tf_.clear(); e->eng.seen_order_.clear(); } e->eng.launch_ahead = value; return STS_OK;
-        case STS_DBG_H2P: e->eng.h2p = value < 0 ? 0 : (value > 5 ? 5 : value); return STS_OK;
+        case STS_DBG_H2P: e->eng.h2p = value < 0 ? 0 : (value > 4 ? 4 : value); return STS_OK;
         case STS_DBG_H2P_TILE: e->eng.h2p_tile = value; return STS_OK;
         case STS_DBG_CHAIN_STREAMS: e->eng.chain_streams_dbg = value; return STS_OK;
         case STS_DBG_TAIL_FUSED: e->eng.tail_fused = value != 0; return STS_OK;
@@ -384,13 +384,14 @@ int sts_debug_conv_h2p(int device, const float* x, int32_t Cin, int32_t L, const
         for (int m = 0; m < members; m++) {
             H2PArgs& a = G.g[m];
             a.xp = dxp; a.xp_ld = L; a.wb = dwb; a.wscale = wscale; a.bias = bias ? db : nullptr; a.res16 = dres16; a.res_ld = L;
-            a.y = dy[m]; a.y_ld = L; a.y16 = dy16[m]; a.y16_ld = L; a.yp = dyp[m]; a.yp_ld = L; a.yp_slope = out_slope;
+            a.y = iters < 0 ? nullptr : dy[m]; a.y_ld = L; a.y16 = dy16[m]; a.y16_ld = L; a.yp = dyp[m]; a.yp_ld = L; a.yp_slope = out_slope;    // (iters < 0: timing with a layer's second conv's outputs only)
             a.Cin = Cin; a.Cout = Cout; a.ntap = k; a.tap_step = dil; a.tap_off = -pad;
         }
         if (!conv_h2p_group_eligible(G)) rc = set_err(STS_EINVAL, "shape not eligible for the pre-split kernel");
         else {
             conv_h2p_group(G, nullptr, tile);
-            if (iters > 0 && ms_out) {
+            if (iters != 0 && ms_out) {
+                if (iters < 0) iters = -iters;
                 hipEvent_t e0, e1;
                 (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
                 (void)hipDeviceSynchronize();
@@ -470,12 +471,13 @@ int sts_debug_conv_h2w(int device, const float* x, int32_t C, int32_t L, const f
         for (int m = 0; m < members; m++) {
             H2WArgs& a = G.g[m];
             a.x16 = dx16; a.x_ld = L; a.wu = dwb; a.wscale = wscale; a.bias = bias ? db : nullptr; a.res16 = dres16; a.res_ld = L;
-            a.y16 = dy16[m]; a.y16_ld = L; a.y = dy[m]; a.y_ld = L; a.in_slope = in_slope; a.out_slope = out_slope; a.C = C; a.k = k; a.dil = dil;
+            a.y16 = dy16[m]; a.y16_ld = L; a.y = iters < 0 ? nullptr : dy[m]; a.y_ld = L; a.in_slope = in_slope; a.out_slope = out_slope; a.C = C; a.k = k; a.dil = dil;
         }
         if (!conv_h2w_group_eligible(G)) rc = set_err(STS_EINVAL, "shape not eligible for the Winograd-domain kernel");
         else {
             conv_h2w_group(G, nullptr);
-            if (iters > 0 && ms_out) {
+            if (iters != 0 && ms_out) {
+                if (iters < 0) iters = -iters;
                 hipEvent_t e0, e1;
                 (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
                 (void)hipDeviceSynchronize();

@@ -24,6 +24,9 @@
 namespace sts {
 
 #define STS_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#ifndef H2W_EXP
+#define H2W_EXP 0       // lab (WRONG results): 1 = weight fragments requested for the first chunk only, 2 = input transform + split for the first chunk only, 4 = no LDS reads after the first chunk
+#endif
 
 constexpr int W_MAXWIN = 128 + MAX_HALO;       // window positions per workgroup at most: WN (2) x 64 outputs + halo
 
@@ -171,13 +174,13 @@ __device__ __forceinline__ void conv_h2w_body(const H2WArgs& a, const SegView& s
                     constexpr int t0 = three ? 3 * sg : 3 * N3 + 2 * (sg - N3);
                     constexpr int q0 = three ? 4 * sg : 4 * N3 + 3 * (sg - N3);          // first pseudo-tap of the segment
                     float d[4][8];
-                    load_d(cc, t0, three, d);
+                    if (!(H2W_EXP & 4) || c == 0) load_d(cc, t0, three, d); else { for (int i = 0; i < 4; i++) for (int e = 0; e < 8; e++) d[i][e] = (float)(i + e); }
                     static_for<0, (three ? 4 : 3)>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
                         constexpr int par = (cc * NTAPW + q0 + j) & 1;
                         u32x4 vb[1][2];
-                        load_a(c * NTAPW + q0 + j + 1, fa[par ^ 1]);                    // past the last step: zeros beyond the descriptor
-                        make_v(d, j, vb);
+                        if (!(H2W_EXP & 1) || c == 0) load_a(c * NTAPW + q0 + j + 1, fa[par ^ 1]);                    // past the last step: zeros beyond the descriptor
+                        if (!(H2W_EXP & 2) || c == 0) make_v(d, j, vb); else { vb[0][0] = fa[par][0][0]; vb[0][1] = fa[par][0][1]; }
                         step_mfmas<1, MW, 1, 2, 2>(acc[j], fa[par], vb);
                     });
                 });

@@ -1094,7 +1094,8 @@ int Engine::run_decode(RunCtx& c, int nw, long Wtot, int maxW, int zoff0, int wl
             // one-workgroup-per-CU residency cost more than the 8 bytes per value it saves); below ~3 tiles per CU (one MB-iSTFT utterance: 294) the
             // entry split and the second conv's two output tensors cost more than the faster K loop returns.  256+ channels: from ~2 tiles per CU on
             // (one HiFi-GAN utterance = 252 tiles needs the K split over two wave groups the staged kernel has).  h2p (lab): 2 = always, 3 / 4 = always for
-            // the 128-channel / the wider stages only, 5 = as 1.
+            // the 128-channel / the wider stages only.  (The 64-channel stage was tried on this path too: it LOSES 1 % to the fused layer kernel at 32 utterances
+            // and 4 % at one -- 4 chunks x k steps are too few to pay for an unfused pair's two epilogues; profiles/r06_h2p_c64_ab.log.)
             const long h2p_tiles = (long)((l2.max_len + 127) / 128) * (up.Cout / 128) * l2.nb * nk;
             const long h2p_min = up.Cout == 128 ? 768 : 512;
             bool h2p_stage = conv_math == 3 && h2p && !per_chain && up.Cout % 128 == 0 && (double)l2.ld * 32.0 < 2.0e9 &&

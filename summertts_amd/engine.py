@@ -335,7 +335,7 @@ def debug_conv_h2p(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], dil
     _check(lib, lib.sts_debug_conv_h2p(device, x.ctypes.data, x.shape[0], L, w.ctypes.data, None if b is None else b.ctypes.data, cout, k, dil,
                                        None if r is None else r.ctypes.data, in_slope, out_slope, tile, members, y.ctypes.data,
                                        y16.ctypes.data, yp.ctypes.data, iters, C.byref(ms)))
-    return y, y16, yp, float(ms.value)
+    return y, y16, yp, float(ms.value)     # (iters < 0: |iters| timed launches WITHOUT the fp32 [C][L] output: a layer's second conv as the engine runs it)
 
 
 def debug_conv_h2w(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], dil: int = 1, res: Optional[np.ndarray] = None,

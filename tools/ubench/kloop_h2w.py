@@ -58,9 +58,9 @@ def time_all():
         for members in (1, 3):
             line = f"{name:10s} members={members}:"
             for tile in (0, 3):
-                *_o, ms = eng.debug_conv_h2p(x, w, b, dil, res, 0.1, 0.1, tile=tile, members=members, iters=10)
+                *_o, ms = eng.debug_conv_h2p(x, w, b, dil, res, 0.1, 0.1, tile=tile, members=members, iters=-10)
                 line += f"  direct t{tile} {ms * 1e3:7.1f} us {members * flops / ms / 1e9:6.1f} TF"
-            *_o, ms = eng.debug_conv_h2w(x, w, b, dil, res, 0.1, 0.1, members=members, iters=10)
+            *_o, ms = eng.debug_conv_h2w(x, w, b, dil, res, 0.1, 0.1, members=members, iters=-10)
             line += f"  | winograd {ms * 1e3:7.1f} us {members * flops / ms / 1e9:6.1f} TF"
             print(line, flush=True)
 
