@@ -918,7 +918,7 @@ def main():
                                  "step_wall_minus_device_stages": 1e3 * (1e3 * stage_wall / stage_steps - sum(stages[k]["ms"] for k in ("text_encoder", "duration", "flow", "decoder"))),
                                  "pcm": "view of the engine's pinned download buffer (sts_pcm_host_view)" if prepared is not None and dist is None else "copied / gathered"},
             "roofline": {
-                "kernel": ("conv_bf3_kernel + conv_bf3_group_kernel + resblock_bf3_kernel (decoder upsamplers + grouped / fused ResBlock convs, "
+                "kernel": ("conv_bf3_kernel + conv_bf3_group_kernel / conv_h2p_group_kernel + resblock_bf3_kernel (decoder upsamplers + grouped staged / pre-split + fused ResBlock convs, "
                            + ("v_mfma_f32_32x32x16_f16 on two-term operands)" if args.conv_math == "f16x2" else "v_mfma_f32_32x32x16_bf16 on split operands)")) if split else
                           ("conv_mfma_kernel + conv_mfma_group_kernel + resblock_wino_kernel / resblock_layer_kernel (decoder upsamplers + "
                            "grouped / fused ResBlock convs, v_mfma_f32_32x32x2_f32)"),

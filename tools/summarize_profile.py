@@ -82,7 +82,7 @@ def classify(names, flow_launches):
         if not ends:
             continue
         for k in range(pre + 1, ends[-1] + 1):
-            if "sum_scale_kernel" not in names[k] and "rocclr" not in names[k]:
+            if "sum_scale_kernel" not in names[k] and "split_planes_kernel" not in names[k] and "rocclr" not in names[k]:      # (the entry split of the pre-split path is not a matrix-core launch: bench.py does not count it either, its time is inside the region)
                 lab[k] = "trunk"
     return lab
 
