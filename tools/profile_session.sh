@@ -6,7 +6,7 @@
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
-B="python bench.py --no-cpu-baseline --no-f32-leg --pipeline-engines 0 $*"
+B="python bench.py --no-cpu-baseline --no-f32-leg --pipeline-engines 0 --configs-block off --min-seconds 0 $*"     # (only the K timed steps + the stage leg of ONE workload in the trace)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- $B --steps 6 --warmup 3 > "$out/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- $B --steps 3 --warmup 1 > "$out/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -- $B --steps 3 --warmup 1 > "$out/write.log" 2>&1

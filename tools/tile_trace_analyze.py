@@ -21,7 +21,7 @@ for i in range(1, len(r)):
     else:
         launches.append(cur); cur = [i]
 launches.append(cur)
-NAMES = {0: ("pro", "kloop", "epi"), 1: ("stage", "conv1", "park", "conv2", "epi"),
+NAMES = {0: ("pro", "kloop", "epi"), 2: ("pro", "kloop", "epi"), 1: ("stage", "conv1", "park", "conv2", "epi"),      # 2 = the pre-split convs (conv_h2p.hip)
          3: ("stage", "wait_ops", "gate_k", "reduce+gate", "1x1+stores"), 4: ("stage_x0", "pre+park", "gate_k", "reduce+gate", "1x1+stores")}
 print(f"{len(r)} complete records, {len(launches)} launches")
 print(" #  kind  grid   wgs  span_us  slot_fill | member: n  start_us(min..max)  dur_us mean/p90  phases mean us ...")
@@ -42,7 +42,7 @@ for li, idx in enumerate(launches):
     ev = ev[np.argsort(ev[:, 0], kind="stable")]
     peak = int(np.cumsum(ev[:, 1]).max())
     fill = (en - st).sum() / (peak * span)
-    print(f"{li:2d} {('conv ', 'fused', '?', 'flow ', 'flow0')[kind]:5s} {int(q[0, 0]):5d} {len(q):5d} {span:8.1f}  {fill:6.2f} (peak {peak} wgs, tick {tick_ns:.3f} ns)")
+    print(f"{li:2d} {('conv ', 'fused', 'h2p  ', 'flow ', 'flow0')[kind]:5s} {int(q[0, 0]):5d} {len(q):5d} {span:8.1f}  {fill:6.2f} (peak {peak} wgs, tick {tick_ns:.3f} ns)")
     for m in np.unique(q[:, 11]):
         s = q[:, 11] == m
         ph = " ".join(f"{n} {((q[s, 5 + k] - q[s, 4 + k]) * tick_ns / 1e3).mean():5.1f}" for k, n in enumerate(NAMES[kind]))
