@@ -1420,6 +1420,70 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
 #define STS_COUT1_CB 8
 #endif
     constexpr int CB = STS_COUT1_CB;
+    // Round 6: a tile that lies wholly inside its utterance on 16-byte-aligned rows stages its 256 own columns through 16-byte loads -- a thread
+    // owns 4 columns of every 4th channel, ALL its loads (Cin / 4 x nsum: 24 for conv_post) in flight at once -- and only the `halo` edge columns
+    // through the scalar form.  Same values, same order of the mean: bit-identical to the scalar staging (profiles/r06_cout1_ab.log).
+    const int lead = -a.tap_off;
+    const bool vec = !(STS_EXP & 2048) && halo > 0 && lead >= 0 && lead <= halo && n0 + 256 <= in_len && a.Cin <= 32;   // (dword-aligned 16-byte loads)
+    if (vec) {
+        const int q4 = (threadIdx.x & 63) * 4, r = threadIdx.x >> 6;
+        const size_t coff = in_base + (size_t)(n0 + q4);
+        const float div = (float)a.nsum;
+        f32x4u v[8], v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool cv = 4 * u + r < a.Cin;
+            const size_t o = coff + (size_t)(4 * u + r) * a.x_ld;
+            const f32x4u z = {0.f, 0.f, 0.f, 0.f};
+            v[u] = cv ? *reinterpret_cast<const f32x4u*>(a.x + o) : z;
+            v1[u] = (cv && a.nsum >= 2) ? *reinterpret_cast<const f32x4u*>(a.xs1 + o) : z;
+            v2[u] = (cv && a.nsum > 2) ? *reinterpret_cast<const f32x4u*>(a.xs2 + o) : z;
+        }
+        // the halo columns (left: lead, right: halo - lead), scalar, requested before the main block is consumed
+        float ev[2] = {0.f, 0.f};
+        const int nedge = halo * a.Cin;     // <= 2 * 256 in every model (halo 6 x 32 channels); more take the loop below
+        int ecol[2], ech[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = threadIdx.x + 256 * u;
+            ech[u] = e / halo;
+            const int ec = e - ech[u] * halo;
+            ecol[u] = ec < lead ? ec : ec + 256;
+            if (e < nedge) {
+                const int pos = n0 + a.tap_off + ecol[u];
+                if (pos >= 0 && pos < in_len) {
+                    const size_t o = in_base + (size_t)pos + (size_t)ech[u] * a.x_ld;
+                    float t = a.x[o];
+                    if (a.nsum >= 2) { t += a.xs1[o]; if (a.nsum > 2) t += a.xs2[o]; t = t / div; }
+                    ev[u] = t;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (4 * u + r < a.Cin) {
+                f32x4u t = v[u];
+                if (a.nsum >= 2) { t = t + v1[u]; if (a.nsum > 2) t = t + v2[u]; t = t / div; }
+                float* dst = xs + (size_t)(4 * u + r) * W + lead + q4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { float s = t[e]; if (a.in_act) s = s < 0.f ? s * a.in_slope : s; dst[e] = s; }
+            }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (threadIdx.x + 256 * u < nedge) { float s = ev[u]; if (a.in_act) s = s < 0.f ? s * a.in_slope : s; xs[(size_t)ech[u] * W + ecol[u]] = s; }
+        for (int e = threadIdx.x + 512; e < nedge; e += 256) {
+            const int ch = e / halo, ec = e - ch * halo, col = ec < lead ? ec : ec + 256;
+            const int pos = n0 + a.tap_off + col;
+            float t = 0.f;
+            if (pos >= 0 && pos < in_len) {
+                const size_t o = in_base + (size_t)pos + (size_t)ch * a.x_ld;
+                t = a.x[o];
+                if (a.nsum >= 2) { t += a.xs1[o]; if (a.nsum > 2) t += a.xs2[o]; t = t / div; }
+            }
+            if (a.in_act) t = t < 0.f ? t * a.in_slope : t;
+            xs[(size_t)ch * W + col] = t;
+        }
+    } else
     for (int col = threadIdx.x; col < W; col += 256) {
         const int pos = n0 + a.tap_off + col;
         const bool ok = pos >= 0 && pos < in_len;

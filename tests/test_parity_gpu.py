@@ -19,6 +19,8 @@ CONV_CASES = [  # Cin, Cout, k, pad, dil, L, stride_transposed, depthwise
     (32, 1, 7, 3, 1, 1000, 0, False), (4, 1, 63, 31, 1, 400, 0, False), (192, 384, 5, 2, 1, 31, 0, False),
     (128, 128, 7, 9, 3, 1500, 0, False), (128, 128, 11, 25, 5, 777, 0, False), (64, 64, 9, 8, 2, 241, 0, False),
     (256, 256, 13, 6, 1, 480, 0, False), (32, 32, 3, 6, 6, 239, 0, False),
+    # long single-output-channel FIRs (conv_cout1_kernel: 16-byte staging of whole tiles, scalar last tile and halo columns)
+    (32, 1, 7, 3, 1, 5003, 0, False), (20, 1, 5, 2, 1, 4500, 0, False), (8, 1, 7, 0, 1, 4700, 0, False),
 ]
 
 
