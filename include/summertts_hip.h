@@ -134,6 +134,7 @@ int sts_set_conv_math(sts_engine* e, int mode);
  *   in round 5 -- the numbers stay retired and answer STS_EINVAL.) */
 enum { STS_DBG_ATTN_BLOCK_MIN_WGS = 1,
        STS_DBG_TAIL_FUSED = 14 /* MB-iSTFT / MS-iSTFT decoders: 1 (default) the tail (spectrum, inverse DFT + overlap-add, synthesis filter, int16 cast) as one launch, 0 three */,
+       STS_DBG_UPS_ROWPH = 15 /* upsamplers (transposed convs, stride 2 / 4 / 8): 1 (default) phases interleaved along the packed rows -> whole-sector stores, 0 phase-major rows */,
        STS_DBG_CHAIN_STREAMS = 13 /* lab: bit i = the ResBlock chains of decoder stage i as per-chain launches on three prioritised streams instead of one grouped launch per layer (-1: off) */,
        STS_DBG_H2P = 11 /* decoder stages of 128 k channels under the two-term fp16 arithmetic: 1 (default) pre-split channel-minor activations (conv_h2p.hip) from ~8 tiles of 128 x 128 per CU on, 2 always (tests), 0 the staged kernels */,
        STS_DBG_H2P_TILE = 12 /* lab: tile code of conv_h2p_group, -1 automatic */,

@@ -165,6 +165,7 @@ int sts_debug_set(sts_engine* e, int key, int value) {
         case STS_DBG_H2P_TILE: e->eng.h2p_tile = value; return STS_OK;
         case STS_DBG_CHAIN_STREAMS: e->eng.chain_streams_dbg = value; return STS_OK;
         case STS_DBG_TAIL_FUSED: e->eng.tail_fused = value != 0; return STS_OK;
+        case STS_DBG_UPS_ROWPH: e->eng.ups_rowph = value != 0; return STS_OK;
         case STS_DBG_MEMO_CLEAR: e->eng.seen_tf_.clear(); e->eng.seen_order_.clear(); return STS_OK;
         case STS_DBG_ATTN_REG: e->eng.attn_reg = value != 0; return STS_OK;
         case STS_DBG_DDS_TAIL: e->eng.dds_tail = value != 0; return STS_OK;
@@ -266,13 +267,30 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         wu.resize((size_t)(wn3 + wn2) * 4 * Cin_pad * Cout_pad);
         wino_pack(w, (long)k * Cin, Cin, 1, Cout, k, Cin, Cin_pad, Cout_pad, wu.data());
     }
+    // mode + 100 (transposed convs of stride 2 / 4 / 8 through the split-operand kernels): the row-interleaved-phase packing (ConvArgs::rowph)
+    const bool rowph = mode >= 100;
+    if (rowph) {
+        mode -= 100;
+        if (!tr || depthwise || Cout != Cout_pad || (stride_t != 2 && stride_t != 4 && stride_t != 8)) return set_err(STS_EINVAL, "row-interleaved phases: transposed conv, stride 2 / 4 / 8, Cout % 32 == 0");
+    }
     // modes 13 / 20..25 / 28..33: the split-bf16 kernel (conv_bf3.hip), automatic tile / tile code (mode - 20)
     const bool h2 = (mode == 50 || (mode >= 60 && mode < 85)) && !depthwise;       // the two-term fp16 form of the same kernel
     if (h2) mode = mode == 50 ? 13 : mode - 40;
     const bool bf3 = (mode == 13 || (mode >= 20 && mode < 45)) && !depthwise;
     std::vector<unsigned char> wb3;
     float h2_scale = 1.0f;
-    if (bf3) {
+    if (rowph && !bf3) return set_err(STS_EINVAL, "row-interleaved phases: split-operand modes only");
+    if (bf3 && rowph) {      // merged row rho = cout * stride + phase, one "phase" of J taps (as model.hip pack_bf3_rowph)
+        const int rows = Cout_pad * stride_t;
+        std::vector<float> wr((size_t)J * Cin_pad * rows, 0.f);
+        for (int ph = 0; ph < stride_t; ph++) for (int j = 0; j < J; j++) for (int ci = 0; ci < Cin_pad; ci++) for (int o = 0; o < Cout_pad; o++)
+            wr[((size_t)j * Cin_pad + ci) * rows + (size_t)o * stride_t + ph] = wp[(((size_t)ph * J + j) * Cin_pad + ci) * Cout_pad + o];
+        wb3.resize(bf3_pack(wr.data(), 1, J, Cin_pad, rows, nullptr, false, h2 ? 1 : 0));
+        bf3_pack(wr.data(), 1, J, Cin_pad, rows, wb3.data(), false, h2 ? 1 : 0, &h2_scale);
+        std::vector<float> br((size_t)rows);
+        for (int r = 0; r < rows; r++) br[r] = bp[r / stride_t];
+        bp.swap(br);
+    } else if (bf3) {
         wb3.resize(bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, nullptr, false, h2 ? 1 : 0));
         bf3_pack(wp.data(), tr ? stride_t : 1, tr ? J : k, Cin_pad, Cout_pad, wb3.data(), false, h2 ? 1 : 0, &h2_scale);
     }
@@ -280,7 +298,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
     float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dwu = nullptr; int* dseg = nullptr;
     int seg[2] = {0, 1};
     bool ok = hipMalloc((void**)&dx, (size_t)Cin * L * 4) == hipSuccess && hipMalloc((void**)&dw, (wn + 1024) * 4) == hipSuccess &&
-              hipMalloc((void**)&db, (size_t)Cout_pad * 4) == hipSuccess && hipMalloc((void**)&dy, (size_t)Cout * Lout * 4) == hipSuccess &&
+              hipMalloc((void**)&db, bp.size() * 4) == hipSuccess && hipMalloc((void**)&dy, (size_t)Cout * Lout * 4) == hipSuccess &&
               hipMalloc((void**)&dseg, 32) == hipSuccess;
     int rc = STS_OK;
     if (ok && !wu.empty()) ok = hipMalloc((void**)&dwu, (wu.size() + 1024) * 4) == hipSuccess;
@@ -289,7 +307,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
     if (rc == STS_OK) {
         (void)hipMemcpy(dx, x, (size_t)Cin * L * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(dw, wp.data(), wn * 4, hipMemcpyHostToDevice);
-        (void)hipMemcpy(db, bp.data(), (size_t)Cout_pad * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
         (void)hipMemset(dseg, 0, 32);
         (void)hipMemcpy(dseg, seg, 8, hipMemcpyHostToDevice);
         (void)hipMemset(dy, 0, (size_t)Cout * Lout * 4);
@@ -306,6 +324,7 @@ int sts_debug_conv1d_bench(int device, const float* x, int32_t Cin, int32_t L, c
         if (dwu) { (void)hipMemcpy(dwu, wu.data(), wu.size() * 4, hipMemcpyHostToDevice); a.wu = dwu; a.wino_n3 = wn3; a.wino_n2 = wn2; }
         if (dwb3) { (void)hipMemcpy(dwb3, wb3.data(), wb3.size(), hipMemcpyHostToDevice); a.wb3 = dwb3; }
         if (h2) { a.math = 1; a.wscale = h2_scale; a.ovf = (unsigned*)dseg + 4; }     // (overflow word: behind the segment table)
+        if (rowph) { a.rowph = stride_t; a.Cout = a.Cout_pad = Cout_pad * stride_t; }
         auto launch = [&]() {
             if (bf3) conv_bf3(a, nullptr, mode == 13 ? -1 : mode - 20);
             else if (mode == 12) conv_wino(a, nullptr);

@@ -137,37 +137,42 @@ static void launch_bf3(const ConvArgs& a, int nphase, hipStream_t st, int pm = 0
 
 // 20: 128 x 128 with K split over two wave groups inside the workgroup (8 waves, 32-channel staged chunks)
 // 24: 256 x 64, K split over two wave groups (8 waves): all rows of a 256-channel conv behind ONE staged window
+// (ConvArgs::rowph: Cout_pad counts the merged rows cout * stride + phase; the tile choice keeps reasoning per phase)
+static inline int bf3_phases(const ConvArgs& a) { return a.transposed ? a.out_stride : 1; }
+static inline int bf3_phase_rows(const ConvArgs& a) { return a.rowph ? a.Cout_pad / a.rowph : a.Cout_pad; }
+static inline int bf3_pick(const ConvArgs& a) { return pick_bf3_tile(bf3_phase_rows(a), a.max_n, (long)a.B * bf3_phases(a), a.transposed != 0, a.math); }
+
 long conv_bf3_blocks(const ConvArgs& a) {
-    const int nphase = a.transposed ? a.out_stride : 1;
-    const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
+    const int nphase = bf3_phases(a);
+    const int tile = bf3_pick(a);
     const int mt = tile == 4 ? 32 : (tile == 3 ? 64 : 128), nt = tile == 4 ? 256 : 128;
-    return (long)((a.max_n + nt - 1) / nt) * ((a.Cout_pad + mt - 1) / mt) * nphase * a.B;
+    return (long)((a.max_n + nt - 1) / nt) * ((bf3_phase_rows(a) + mt - 1) / mt) * nphase * a.B;
 }
 
 // the tiles instantiated with the summed-input staging: the ones the automatic choice gives a transposed conv (upsamplers)
 bool conv_bf3_takes_sum(const ConvArgs& a) {
     if (!conv_bf3_eligible(a) || a.in_reflect || a.nsum < 2 || a.nsum > 3 || !a.xs1 || (a.nsum == 3 && !a.xs2)) return false;
-    const int nphase = a.transposed ? a.out_stride : 1;
-    const int tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
+    const int nphase = bf3_phases(a);
+    const int tile = bf3_pick(a);
     // every workgroup that stages a window forms the mean itself (3 reads + a division per staged value), so the fold only pays where a
     // window is staged once or twice: the phase-merged tiles whose row space (phases x Cout) fits one or two workgroups.  Measured
     // (profiles/r04_ab_log.md): stage-2 upsampler, 8 phases x 128 rows on 128-row tiles: 61 us folded vs 48 + 6; stages 3 / 4: 34 vs 25.5 + 14
-    if (tile == 22) return (long)nphase * a.Cout_pad <= 2 * 128;
-    if (tile == 23) return (long)nphase * a.Cout_pad <= 2 * 64;
+    if (tile == 22) return (long)nphase * bf3_phase_rows(a) <= 2 * 128;
+    if (tile == 23) return (long)nphase * bf3_phase_rows(a) <= 2 * 64;
     return false;
 }
 
 void conv_bf3(const ConvArgs& a, hipStream_t st, int tile) {
-    const int nphase = a.transposed ? a.out_stride : 1;
+    const int nphase = a.rowph ? 1 : bf3_phases(a);        // (row-interleaved phases: ONE row space, launched as a plain conv of Cout_pad merged rows)
     if (a.max_n <= 0 || a.B <= 0) return;
-    if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
+    if (!bf3_tile_ok(tile) || (a.math == 1 && !h2_tile(tile))) tile = bf3_pick(a);
     if (tile >= 8 && tile < 16 && a.Cin_pad % 32 != 0) tile -= 8;
-    if (a.nsum >= 2 && tile != 22 && tile != 23) tile = pick_bf3_tile(a.Cout_pad, a.max_n, (long)a.B * nphase, a.transposed != 0, a.math);
+    if (a.nsum >= 2 && tile != 22 && tile != 23) tile = bf3_pick(a);
     switch (tile) {
         case 20: if (a.Cin_pad % 32 == 0) { launch_bf3<2, 2, 2, 2, 2, 2, true>(a, nphase, st); break; } launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         // phase-merged rows (transposed convs): 22: 128 x 128   23: 64 x 128 as two 32-row waves x 2   (lab: 21: 256 x 128, 8 waves)
-        case 22: launch_bf3<2, 2, 2, 2, 1, 1, true, true>(a, nphase, st, 1); break;
-        case 23: launch_bf3<1, 2, 2, 2, 1, 1, true, true>(a, nphase, st, 1); break;
+        case 22: launch_bf3<2, 2, 2, 2, 1, 1, true, true>(a, nphase, st, a.rowph ? 0 : 1); break;
+        case 23: launch_bf3<1, 2, 2, 2, 1, 1, true, true>(a, nphase, st, a.rowph ? 0 : 1); break;
         case 0: launch_bf3<2, 2, 2, 2, 1, 1, true>(a, nphase, st); break;
         case 3: launch_bf3<2, 2, 1, 2, 1, 1, true>(a, nphase, st); break;
 #ifdef STS_EXPERIMENTS      // tiles no automatic choice selects (measured ties / losses, profiles/r03_*tile_sweep.log): lab build only

@@ -293,7 +293,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int mtile
     const int nrt = a.Cout_pad / 32;
 
     // ---- A fragments: step s = (16-channel chunk) * ntap + tap is one contiguous block of nrt * 3 KB
-    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed ? a.out_stride : 1) * nsteps_all * nrt * ABLK));
+    const rsrc_t wrs = make_rsrc(a.wb3, (unsigned)((size_t)(a.transposed && !a.rowph ? a.out_stride : 1) * nsteps_all * nrt * ABLK));
     // (the wave's row tile goes into the per-lane offset: the compiler cannot prove tid >> 6 wave-uniform and would wrap
     // every load in a readfirstlane loop if it sat in the scalar offset)
     const unsigned a_voff = wvalid ? (unsigned)lane * 16u + ((unsigned)phase * (unsigned)nsteps_all * (unsigned)nrt + (unsigned)(mbase >> 5)) * ABLK : kOOB;

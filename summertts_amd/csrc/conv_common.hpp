@@ -107,6 +107,7 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], const int lane) {
     const float s0 = dpp_quad_1032(lo ? v[0] : v[1]), s1 = dpp_quad_1032(lo ? v[2] : v[3]);
     if (lo) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
 }
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access with dword alignment (packed rows start anywhere)
 
 // Epilogue on the accumulator registers (C/D layout of every 32x32 MFMA: col (time) = lane & 31,
@@ -217,6 +218,51 @@ __device__ __forceinline__ void tile_epilogue_impl(const ConvArgs& a, f32x16 (&a
                     }
                 }
             });
+        });
+        return;
+    }
+    if (a.rowph && a.epi == EPI_STORE) {
+        // Polyphase transposed conv whose packed rows interleave the phases (ConvArgs::rowph): tile row rho = cout * s + phase.  A lane's four
+        // consecutive accumulator rows (4 half + 0..3 of every 8) are four consecutive OUTPUT POSITIONS of one channel for s = 4 / 8 (two
+        // positions of two channels for s = 2), columns n -> positions n s + phase: a wave's store covers contiguous runs of each row
+        // (whole 32-byte sectors) instead of one dword per lane at a stride of s dwords.  Same value per element as the form below.
+        const int s = a.out_stride, sh = s == 8 ? 3 : (s == 4 ? 2 : 1);
+        static_for<0, MW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (mbase + i * 32 < a.Cout_pad) {
+                f32x4u bv[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int rho0 = mbase + i * 32 + 8 * g + 4 * half;
+                    bv[g] = a.bias ? *(const f32x4u*)(a.bias + rho0) : f32x4u{0.f, 0.f, 0.f, 0.f};        // bias per merged row, padded to Cout_pad
+                }
+                static_for<0, NW>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const int n = ncol0 + q * 32 + l31;
+                    if (n < n_count) {
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const int rho0 = mbase + i * 32 + 8 * g + 4 * half;
+                            if (rho0 >= a.Cout) continue;
+                            const f32x4u v = {acc[i][q][4 * g] + bv[g][0], acc[i][q][4 * g + 1] + bv[g][1], acc[i][q][4 * g + 2] + bv[g][2], acc[i][q][4 * g + 3] + bv[g][3]};
+                            const int co = rho0 >> sh;
+                            const int pos = n * s + a.out_off + (rho0 & (s - 1));
+                            if (s >= 4) {
+                                float* yp = a.y + (size_t)co * a.y_ld + out_base + pos;
+                                if (pos >= 0 && pos + 3 < out_len) *(f32x4u*)yp = v;
+                                else { for (int e = 0; e < 4; e++) if (pos + e >= 0 && pos + e < out_len) yp[e] = v[e]; }
+                            } else {
+#pragma unroll
+                                for (int c2 = 0; c2 < 2; c2++) {
+                                    float* yp = a.y + (size_t)(co + c2) * a.y_ld + out_base + pos;
+                                    if (pos >= 0 && pos + 1 < out_len) *(f32x2u*)yp = f32x2u{v[2 * c2], v[2 * c2 + 1]};
+                                    else { for (int e = 0; e < 2; e++) if (pos + e >= 0 && pos + e < out_len) yp[e] = v[2 * c2 + e]; }
+                                }
+                            }
+                        }
+                    }
+                });
+            }
         });
         return;
     }

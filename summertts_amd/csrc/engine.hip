@@ -173,6 +173,13 @@ void Engine::conv(const DConv& c, const float* x, const Lvl& lin, float* y, cons
     // at which they stop being launch-latency-bound (a batch of a few dozen utterances); conv_math 2 = wherever eligible (tests)
     const bool use_bf3 = conv_mode == 0 && conv_math != 1 && o.tile < 0 && conv_bf3_eligible(a) &&
                          (in_mfma_region_ || conv_math == 2 || conv_bf3_blocks(a) >= 384);
+    if (use_bf3 && c.transposed && ups_rowph && a.epi == EPI_STORE && !a.ubias && (a.math == 1 ? c.wh2r : c.wb3r)) {
+        // upsamplers: the copy whose rows interleave the phases (rho = cout * stride + phase) -- same sums in the same order, whole-sector stores
+        a.wb3 = a.math == 1 ? c.wh2r : c.wb3r;
+        a.bias = c.bias ? c.bias_r : nullptr;
+        a.Cout = a.Cout_pad = c.Cout_pad * c.stride;
+        a.rowph = c.stride;
+    }
     if (a.nsum >= 2 && !(use_bf3 ? conv_bf3_takes_sum(a) : (!can_mfma && conv_cout1_takes(a)))) {
         // this conv's kernel cannot form the mean of its input terms while staging: one launch materialises it (the round-3 form)
         const float* r[3] = {x, o.sum1, o.sum2};

@@ -105,6 +105,7 @@ public:
     void nap_before_wait(int which, long phonemes);
     void note_wait(int which, long phonemes, double waited_us, bool was_ready_at_wake);
     int final_sync(long phonemes);
+    int ups_rowph = 1;                 // upsamplers: 1 the row-interleaved-phase copies (ConvArgs::rowph: whole-sector stores), 0 phase-major rows (sts_debug_set)
     int tail_fused = 1;                // MB-iSTFT / MS-iSTFT tail: 1 spectrum + inverse DFT / overlap-add + synthesis filter + int16 cast as one launch, 0 three (sts_debug_set)
     int chain_streams_dbg = -1;        // lab: stage mask -- the chains of the masked decoder stages as per-chain launches on three prioritised streams instead of grouped launches
     int h2p = 1;                       // 1: the wide ResBlock stages (C % 128 == 0) on pre-split channel-minor activations (conv_h2p.hip; two-term fp16 arithmetic only), 0: the staged kernels

@@ -74,6 +74,11 @@ struct ConvArgs {
     // (0 / 1: plain x) -- the mean over a decoder stage's ResBlock chains (Generator_hifigan.cpp:159-173) formed in the staging code
     // of the conv that consumes it instead of by a launch of its own.  Taken by conv_bf3 (conv_bf3_takes_sum) and conv_cout1 only.
     const float* xs1; const float* xs2; int nsum;
+    // polyphase transposed conv with ROW-INTERLEAVED phases (conv_bf3 only; 0 = off, else == out_stride in {2, 4, 8}): the packed rows are
+    // rho = cout * stride + phase (Cout / Cout_pad count those merged rows, bias is per merged row), so a lane's four consecutive accumulator
+    // rows are consecutive OUTPUT POSITIONS of one channel and the tile leaves through 16-byte (stride 2: 8-byte) stores that fill whole
+    // sectors -- the phase-major form writes one dword per lane at a stride of `stride` dwords (round 6, profiles/r06_upsampler_rowph.log)
+    int rowph;
 };
 
 // Segmented Winograd F(2,3): a k-tap filter is cut into n3 three-tap segments followed by n2 two-tap segments

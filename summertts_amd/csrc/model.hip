@@ -92,7 +92,7 @@ struct Store {
         int device = 0;
         (void)hipGetDevice(&device);
         vmm = vmm_probe(device, &gran);
-        cap = vmm ? blob_floats * 8 + (16u << 20) : blob_floats * 6 + (8u << 20);
+        cap = vmm ? blob_floats * 9 + (16u << 20) : blob_floats * 7 + (8u << 20);
         host.p = (float*)calloc(cap, sizeof(float));
         if (!host.p) return false;
         if (vmm) {
@@ -100,7 +100,7 @@ struct Store {
             void* va = nullptr;
             if (hipMemAddressReserve(&va, reserved, 0, nullptr, 0) == hipSuccess) { dev = (float*)va; return true; }
             (void)hipGetLastError();
-            vmm = false; cap = blob_floats * 6 + (8u << 20);
+            vmm = false; cap = blob_floats * 7 + (8u << 20);
         }
         return hipMalloc((void**)&dev, cap * sizeof(float)) == hipSuccess;
     }
@@ -220,6 +220,39 @@ bool pack_bf3(Store& st, DConv& d, bool perm_k = false) {
     if (!q) return false;
     bf3_pack(wh, nphase, ntap, d.Cin_pad, d.Cout_pad, q, perm_k, 1, &d.h2_scale);
     if (perm_k) d.wh2p = hptr; else d.wh2 = hptr;
+    return true;
+}
+
+// row-interleaved-phase copies of a polyphase transposed conv (ConvArgs::rowph): merged row rho = cout * stride + phase, one "phase" of J taps
+bool pack_bf3_rowph(Store& st, DConv& d) {
+    if (!d.transposed || !d.w || !d.wb3 || d.Cin != d.Cin_pad || d.Cout != d.Cout_pad || (d.stride != 2 && d.stride != 4 && d.stride != 8)) return true;
+    const int s = d.stride, rows = d.Cout_pad * s;
+    const float* wh = st.host.data() + (d.w - st.dev);        // [phase][J][Cin_pad][Cout_pad]
+    std::vector<float> wr((size_t)d.J * d.Cin_pad * rows);
+    for (int ph = 0; ph < s; ph++)
+        for (int j = 0; j < d.J; j++)
+            for (int ci = 0; ci < d.Cin_pad; ci++) {
+                const float* src = wh + (((size_t)ph * d.J + j) * d.Cin_pad + ci) * d.Cout_pad;
+                float* dst = wr.data() + ((size_t)j * d.Cin_pad + ci) * rows + ph;
+                for (int co = 0; co < d.Cout_pad; co++) dst[(size_t)co * s] = src[co];
+            }
+    const size_t bytes = bf3_pack(nullptr, 1, d.J, d.Cin_pad, rows, nullptr);
+    const float* dptr = nullptr;
+    float* p = st.alloc((bytes + 3) / 4 + 1024, &dptr);
+    if (!p) return false;
+    bf3_pack(wr.data(), 1, d.J, d.Cin_pad, rows, p, false);
+    const size_t hbytes = bf3_pack(nullptr, 1, d.J, d.Cin_pad, rows, nullptr, false, 1);
+    const float* hptr = nullptr;
+    float* q = st.alloc((hbytes + 3) / 4 + 1024, &hptr);
+    if (!q) return false;
+    float sc = 1.0f;
+    bf3_pack(wr.data(), 1, d.J, d.Cin_pad, rows, q, false, 1, &sc);
+    if (sc != d.h2_scale) return true;                        // (same weights, same largest magnitude: cannot differ; keep the phase-major copy if it does)
+    const float* bptr = nullptr;
+    float* b = st.alloc((size_t)rows, &bptr);
+    if (!b) return false;
+    if (d.bias) { const float* bh = st.host.data() + (d.bias - st.dev); for (int r = 0; r < rows; r++) b[r] = bh[r / s]; }
+    d.wb3r = dptr; d.wh2r = hptr; d.bias_r = bptr;
     return true;
 }
 
@@ -509,7 +542,7 @@ bool load_model(const float* blob, int64_t nfloats, Model& m) {
         if (!r.ok || u <= 0 || k != h.k) FAIL("upsampler");
         const int pad = (int)floor((float)(k - u) / (2.0));   // header stride/padding overridden (Generator_hifigan.cpp:76-82)
         if (k - 2 * pad != u) FAIL("upsampler with (k - stride) odd is not length-preserving");
-        if (!pack_convT(st, h, u, pad, m.ups[i]) || !pack_bf3(st, m.ups[i])) FAIL("upsampler pack");
+        if (!pack_convT(st, h, u, pad, m.ups[i]) || !pack_bf3(st, m.ups[i]) || !pack_bf3_rowph(st, m.ups[i])) FAIL("upsampler pack");
         m.hop_total *= u;
     }
     m.rb.resize((size_t)m.n_up * m.n_resk);

@@ -38,6 +38,8 @@ struct DConv {
     const void* wh2 = nullptr;      // two-term fp16 copy in wb3's layout (conv_bf3.hip MATH 1), weights scaled by 1 / h2_scale (a power of two)
     const void* wh2p = nullptr;     // ... in wb3p's k order
     float h2_scale = 1.0f;
+    // transposed convs with stride 2 / 4 / 8: the same two copies with row-interleaved phases (ConvArgs::rowph) and the bias per merged row
+    const void* wb3r = nullptr; const void* wh2r = nullptr; const float* bias_r = nullptr;
     double macs_per_out = 0;   // true-tap MACs per output position (all output channels)
 };
 struct DLn { int C = 0; const float* g = nullptr; const float* b = nullptr; };

@@ -257,7 +257,7 @@ class Synthesizer:
 
     def debug_set(self, key: str, value: int):
         """Test hooks (include/summertts_hip.h sts_debug_set): 'attn_block_min_wgs' | 'flow_fused' | 'launch_ahead' | ..."""
-        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "flow_fused": 5, "launch_ahead": 6, "attn_reg": 7, "dds_tail": 8, "pcm_direct": 9, "memo_clear": 10, "h2p": 11, "h2p_tile": 12, "chain_streams": 13, "tail_fused": 14}[key], int(value)))
+        _check(self.lib, self.lib.sts_debug_set(self.h, {"attn_block_min_wgs": 1, "flow_fused": 5, "launch_ahead": 6, "attn_reg": 7, "dds_tail": 8, "pcm_direct": 9, "memo_clear": 10, "h2p": 11, "h2p_tile": 12, "chain_streams": 13, "tail_fused": 14, "ups_rowph": 15}[key], int(value)))
 
     def set_profiling(self, on):
         """False / True: no / all eight stage events per run; 2: only the two events around the decoder's matrix-core region (the

@@ -685,6 +685,64 @@ def test_pre_split_trunk_path_matches_reference_golden(path):
     syn.close()
 
 
+UPS_CASES = [  # Cin, Cout, k, pad, stride, L      (HiFi-GAN: k16 s8 / k4 s2; MB-iSTFT: k16 s4; tiny models: k8 s4; odd lengths -> ragged tiles)
+    (512, 256, 16, 4, 8, 668), (256, 128, 16, 4, 8, 1301), (128, 64, 4, 1, 2, 3001), (64, 32, 4, 1, 2, 4099), (256, 128, 16, 6, 4, 700),
+    (64, 32, 8, 2, 4, 77), (32, 32, 16, 4, 8, 5), (96, 64, 4, 1, 2, 1), (64, 96, 11, 3, 4, 130),
+]
+
+
+@pytest.mark.parametrize("case", UPS_CASES, ids=str)
+def test_upsampler_row_interleaved_phases_equal_the_phase_major_form(case):
+    """Round 6: transposed convs of stride 2 / 4 / 8 through the split-operand kernels with the phases interleaved along the packed rows
+    (ConvArgs::rowph: whole-sector stores).  Same products in the same order per output value: BIT-identical to the phase-major packing for every
+    tile shape that does not split K, both arithmetics, and within the usual bound of a float64 transposed conv.
+    /root/reference/src/nn_op/nn_conv1d_transposed.cpp:24-53."""
+    import torch
+    import torch.nn.functional as F
+    ci, co, k, pad, st, L = case
+    rng = np.random.default_rng(ci * 31 + co + k + L)
+    x = (rng.standard_normal((ci, L)) * rng.uniform(0.05, 3.0, (ci, 1))).astype(np.float32)
+    w = (rng.standard_normal((co, k, ci)) / np.sqrt(k * ci / st)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    ref = F.conv_transpose1d(torch.from_numpy(x).double()[None], torch.from_numpy(w).double().permute(2, 0, 1).contiguous(), torch.from_numpy(b).double(),
+                             stride=st, padding=pad)[0].numpy()
+    for auto, codes in ((13, (20, 23, 42, 43)), (50, (60, 63, 82, 83))):       # split-bf16 / two-term fp16: automatic tile, 128 x 128, 64 x 128, the summed-input tiles
+        y0 = engine.debug_conv1d(x, w, b, pad, 1, st, False, in_slope=0.1, in_act=1, mode=codes[0])
+        for mode in codes:
+            y = engine.debug_conv1d(x, w, b, pad, 1, st, False, in_slope=0.1, in_act=1, mode=100 + mode)
+            assert y.shape == ref.shape
+            assert np.array_equal(y, y0), (case, mode, np.abs(y - y0).max())
+        y = engine.debug_conv1d(x, w, b, pad, 1, st, False, in_slope=0.1, in_act=1, mode=100 + auto)      # (may pick the K-split tile: other order)
+        xa = np.where(x < 0, x * np.float32(0.1), x).astype(np.float32)
+        refa = F.conv_transpose1d(torch.from_numpy(xa).double()[None], torch.from_numpy(w).double().permute(2, 0, 1).contiguous(),
+                                  torch.from_numpy(b).double(), stride=st, padding=pad)[0].numpy()
+        assert np.abs(y - refa).max() <= 2e-5 and np.abs(y0 - refa).max() <= 2e-5, (case, auto, np.abs(y - refa).max())
+    y = engine.debug_conv1d(x, w, None, pad, 1, st, False, mode=150)       # no bias
+    assert np.abs(y - (ref - b[:, None])).max() <= 2e-5
+
+
+@pytest.mark.parametrize("kind", ["hifigan_sdp", "mbb_fix", "ms_hifigan_sdp"])
+def test_engine_upsamplers_row_interleaved_on_off_identical(kind):
+    """The engine's upsamplers with and without the row-interleaved packing (sts_debug_set ups_rowph): the same PCM, bit for bit, at one
+    utterance (K-split tile on the first upsampler in both forms) and in a ragged batch, under both split-operand arithmetics."""
+    cfg = sb.full_cfg(kind)
+    blob = sb.make_blob(cfg, 11)
+    syn = engine.Synthesizer(blob)
+    batch = [sb.synthetic_ids(t, cfg.vocab, salt=u) for u, t in enumerate((37, 9, 64))]
+    sids = [0, 1, 2] if cfg.is_ms else [0, 0, 0]
+    for math in ("f16x2", "bf16x3"):
+        syn.set_conv_math(math)
+        out = {}
+        for on in (1, 0):
+            syn.debug_set("ups_rowph", on)
+            syn.run_batch([batch[0]], [sids[0]], [1.0])
+            one = syn.pcm_host().copy()
+            syn.run_batch(batch, sids, [1.0, 0.9, 1.1])
+            out[on] = (one, syn.pcm_host().copy())
+        assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1]), (kind, math)
+    syn.close()
+
+
 @pytest.mark.parametrize("C,k,dil,L", [(128, 3, 1, 777), (128, 7, 3, 1500), (128, 11, 5, 300), (256, 3, 1, 1029), (256, 11, 5, 97), (128, 3, 1, 5), (512, 3, 1, 130)])
 def test_pre_split_conv_against_float64(C, k, dil, L):
     """One conv through split_planes + conv_h2p_group, every tile code, all three output forms (fp32 [C][L], the channel-minor fp32 copy, the
