@@ -27,8 +27,24 @@ int tile_trace_bind_resblock(long long* buf, unsigned capacity_records) { return
 // workgroup per tile (the launch runs as 4-5 rounds whose boundaries idle half the chip, slot fill 0.75-0.82 in the tile trace) --
 // +6 % SLOWER at one utterance, +10 % at batch 32: the tile body inlined into a loop spills 150 bytes per lane at 168 registers and
 // the claim adds a barrier pair per tile, which costs more than the round boundaries it removes.
+// Round 6 (profiles/r06_narrow_stage_ab.log), at 32 utterances where these two stages are 35 % of the step at 0.24-0.30 of the matrix peak:
+//   * pieces compiled out (STS_RB_EXP): without its MFMAs the 64-channel launch takes 1.87 ms of 4.42, without operand loads in the K loops 3.72,
+//     i.e. memory skeleton + matrix time with NO overlap although three workgroups share a CU -- the signature of the power cap:
+//     overlap does not remove joules;
+//   * weight fragments 3 and 4 steps ahead instead of 1 (STS_RB_ADEPTH): no difference -- the K loop is not waiting for L2;
+//   * first-round workgroups of a SIMD started 4-64 us apart (lockstep hypothesis): no difference at batch, slower at one utterance;
+//   * the residual requested right behind the window's loads instead of before conv2 (kept): -0.8 % at 32 utterances, 28 registers fewer.
 #ifndef STS_RB_WAVES
 #define STS_RB_WAVES 3
+#endif
+#ifndef STS_RB_ADEPTH
+#define STS_RB_ADEPTH 2      // weight-fragment ring: steps in flight (round 6: 3 and 4 measured, no difference -- profiles/r06_narrow_stage_ab.log)
+#endif
+#ifndef STS_RB_EXP
+#define STS_RB_EXP 0         // lab, TIMING only (wrong results): 1 = no B-fragment reads inside the K loops, 2 = no A-fragment loads, 4 = no MFMAs
+#endif
+#ifndef STS_RB_RES_LATE
+#define STS_RB_RES_LATE 0     // lab: 1 = the residual requested before conv2's K loop (rounds 3-5)
 #endif
 template <int MW, int WM, int NW, int WN, int MATH = 0>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW == 1 ? STS_RB_WAVES : 2, MW == 1 ? STS_RB_WAVES : 2))) void resblock_bf3_kernel(ResLayerGroup G, int nx, int wst, int interleave) {
@@ -67,6 +83,26 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW
     const int plane1 = wst * 32, chunk1 = NPB * plane1;
     const unsigned ld4 = (unsigned)G.ld * 4u;
     float amax = 0.f;
+
+    // ---- weight fragments: a ring of AD steps.  Round 6: the K loops were A-LATENCY-bound -- a step of one wave is 6 MFMAs (0.09 us) and three
+    // waves share a SIMD, but the tile trace showed 0.39-0.45 us per step = one L2 round trip: with the next step's fragments requested only
+    // one step ahead every wave waited for them every step.  Now AD - 1 steps ahead, conv1's first fragments requested before the window is
+    // staged and conv2's before the intermediate is parked.
+    constexpr int AD = (MATH == 1 && MW == 1) ? STS_RB_ADEPTH : 2;      // (three-plane weights / two row tiles per wave: no registers for a deeper ring)
+    const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * ABLK;
+    u32x4 fa[AD][MW][NPA], fb[2][NW][NPB];
+    const int nsteps1 = NCH * a.k1, nsteps2 = NCH * a.k2;
+    const rsrc_t wrs1 = make_rsrc(a.wb1, (unsigned)(nsteps1 * NRT) * ABLK), wrs2 = make_rsrc(a.wb2, (unsigned)(nsteps2 * NRT) * ABLK);
+    auto load_a = [&](const rsrc_t& wrs, int s, u32x4 (&dst)[MW][NPA]) {          // past the end: zeros beyond the descriptor
+        const unsigned sb = (unsigned)s * ((unsigned)NRT * ABLK);
+#pragma unroll
+        for (int i = 0; i < MW; i++)
+#pragma unroll
+            for (int pl = 0; pl < NPA; pl++)
+                dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)i * ABLK + (unsigned)(pl * 1024)), 0));
+    };
+#pragma unroll
+    for (int r = 0; r < AD - 1; r++) load_a(wrs1, r, fa[r]);
 
     // ---- stage the whole window: item t = (chunk, slot of 32 positions), wave w owns items w, w + NWAVE, ...
     {
@@ -111,6 +147,43 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW
         }
     }
 
+    // The residual (raw x of the output columns; the staged copy is activated and split) and conv2's bias, in the transposed-quad layout of the
+    // epilogue.  Round 3 requested them before conv2's K loop (they arrive under its MFMAs); round 6 requests them HERE, right behind the window's
+    // own loads: by conv2 the XCD's L2 (4 MB under 32 CUs x 3 resident windows + their output tiles) has dropped the window, and the re-read went
+    // to the fabric -- a third of the launch's fetch bytes (rocprofv3 FETCH_SIZE: 146-156 MB per 64-channel launch at one utterance = 1.25 x the
+    // input for the windows + 1 x for the residual).  Issued now, the lines are still in flight / just filled: one fabric read serves both.
+    const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
+    f32x4u xres[MW][NW][4];
+    float b2v[MW][4];
+#if STS_RB_RES_LATE
+    auto request_residual = [&]() {
+#else
+    {
+#endif
+#pragma unroll
+    for (int i = 0; i < MW; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int row = mbase + i * 32 + 8 * g + 4 * half + lane4;
+            b2v[i][g] = a.b2 ? a.b2[row] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const int col = wn * NW * 32 + q * 32 + m4;
+                const int pos = n0 + col;
+                xres[i][q][g] = f32x4u{0.f, 0.f, 0.f, 0.f};
+                if (col < NT && pos < len) {
+                    const float* xp = a.x + (size_t)row * G.ld + base + pos;
+                    if (col + 3 < NT && pos + 3 < len) xres[i][q][g] = *(const f32x4u*)xp;
+                    else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) xres[i][q][g][e] = xp[e]; }
+                }
+            }
+        }
+#if STS_RB_RES_LATE
+    };
+#else
+    }
+#endif
+
     f32x16 acc[MW][NW];
 #pragma unroll
     for (int i = 0; i < MW; i++)
@@ -118,24 +191,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW
         for (int q = 0; q < NW; q++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][q][r] = 0.f;
-    const unsigned a_voff = (unsigned)lane * 16u + (unsigned)(mbase >> 5) * ABLK;
-    u32x4 fa[2][MW][NPA], fb[2][NW][NPB];
     auto mfmas = [&](u32x4 (&ac)[MW][NPA], u32x4 (&bc)[NW][NPB]) { step_mfmas<MATH, MW, NW, NPA, NPB>(acc, ac, bc); };
     __syncthreads();
     TT_STAMP(1);
 
     // ================= phase 1: conv1 on the P1 columns [n0 - h2, n0 - h2 + P1) =================
     {
-        const int nsteps = NCH * a.k1;
-        const rsrc_t wrs = make_rsrc(a.wb1, (unsigned)(nsteps * NRT) * ABLK);
-        auto load_a = [&](int s, u32x4 (&dst)[MW][NPA]) {
-            const unsigned sb = (unsigned)s * ((unsigned)NRT * ABLK);
-#pragma unroll
-            for (int i = 0; i < MW; i++)
-#pragma unroll
-                for (int pl = 0; pl < NPA; pl++)
-                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)i * ABLK + (unsigned)(pl * 1024)), 0));
-        };
         const int p0 = wn * NW * 32 + l31;
         auto load_b = [&](int c, int j, u32x4 (&dst)[NW][NPB]) {
             const int p = p0 + j * d;
@@ -146,22 +207,23 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW
                 for (int pl = 0; pl < NPB; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * plane1 + q * 1024);
         };
         int sj = 0, sc = 0;
-        load_a(0, fa[0]);
         load_b(0, 0, fb[0]);
-        for (int s = 0; s < nsteps; s += 2)
-            static_for<0, 2>([&](auto uc) {
+        for (int s = 0; s < nsteps1; s += 2 * AD)
+            static_for<0, 2 * AD>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                if (s + u < nsteps) {
+                if (s + u < nsteps1) {
                     int nj = sj + 1, nc = sc;
                     if (nj == a.k1) { nj = 0; nc = sc + 1; }
-                    load_a(s + u + 1, fa[(u + 1) % 2]);                       // past the end: zeros beyond the descriptor
-                    load_b(nc < NCH ? nc : 0, nj, fb[(u + 1) % 2]);
+                    if (!(STS_RB_EXP & 2)) load_a(wrs1, s + u + AD - 1, fa[(u + AD - 1) % AD]);
+                    if (!(STS_RB_EXP & 1)) load_b(nc < NCH ? nc : 0, nj, fb[(u + 1) % 2]);
                     __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs (the scheduler would sink them)
-                    mfmas(fa[u % 2], fb[u % 2]);
+                    if (!(STS_RB_EXP & 4)) mfmas(fa[(STS_RB_EXP & 2) ? 0 : u % AD], fb[(STS_RB_EXP & 1) ? 0 : u % 2]);
                     sj = nj; sc = nc;
                 }
             });
     }
+#pragma unroll
+    for (int r = 0; r < AD - 1; r++) load_a(wrs2, r, fa[r]);          // conv2's first fragments travel under the park phase
     TT_STAMP(2);
     __syncthreads();          // every wave is done reading the staged window (the parked intermediate overwrites it)
     // ---- park: bias, conv2's input activation, conv2's zero padding outside [0, len), split
@@ -209,43 +271,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW
     __syncthreads();
     TT_STAMP(3);
 
-    // The residual (raw x of the output columns; the staged copy was activated and split) and conv2's bias are requested BEFORE
-    // conv2's K loop, in the transposed-quad layout of the epilogue below: they arrive under the MFMAs instead of costing the
-    // epilogue a memory round trip (round 3, tools/tile_trace.py: epilogue 4.4 us of a 19 us 32-channel tile)
-    const int lane4 = l31 & 3, m4 = (l31 >> 2) * 4;
-    f32x4u xres[MW][NW][4];
-    float b2v[MW][4];
-#pragma unroll
-    for (int i = 0; i < MW; i++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int row = mbase + i * 32 + 8 * g + 4 * half + lane4;
-            b2v[i][g] = a.b2 ? a.b2[row] : 0.f;
-#pragma unroll
-            for (int q = 0; q < NW; q++) {
-                const int col = wn * NW * 32 + q * 32 + m4;
-                const int pos = n0 + col;
-                xres[i][q][g] = f32x4u{0.f, 0.f, 0.f, 0.f};
-                if (col < NT && pos < len) {
-                    const float* xp = a.x + (size_t)row * G.ld + base + pos;
-                    if (col + 3 < NT && pos + 3 < len) xres[i][q][g] = *(const f32x4u*)xp;
-                    else { for (int e = 0; e < 4; e++) if (col + e < NT && pos + e < len) xres[i][q][g][e] = xp[e]; }
-                }
-            }
-        }
-
+#if STS_RB_RES_LATE
+    request_residual();
+#endif
     // ================= phase 2: conv2 (dilation 1) out of the parked intermediate =================
     {
-        const int nsteps = NCH * a.k2;
-        const rsrc_t wrs = make_rsrc(a.wb2, (unsigned)(nsteps * NRT) * ABLK);
-        auto load_a = [&](int s, u32x4 (&dst)[MW][NPA]) {
-            const unsigned sb = (unsigned)s * ((unsigned)NRT * ABLK);
-#pragma unroll
-            for (int i = 0; i < MW; i++)
-#pragma unroll
-                for (int pl = 0; pl < NPA; pl++)
-                    dst[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)a_voff, (int)(sb + (unsigned)i * ABLK + (unsigned)(pl * 1024)), 0));
-        };
         const int p0 = wn * NW * 32 + l31;
         auto load_b = [&](int c, int j, u32x4 (&dst)[NW][NPB]) {
             const int p = p0 + j;
@@ -256,18 +286,17 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(MW
                 for (int pl = 0; pl < NPB; pl++) dst[q][pl] = *(const u32x4*)(sb + pl * PLANE2 + q * 1024);
         };
         int sj = 0, sc = 0;
-        load_a(0, fa[0]);
         load_b(0, 0, fb[0]);
-        for (int s = 0; s < nsteps; s += 2)
-            static_for<0, 2>([&](auto uc) {
+        for (int s = 0; s < nsteps2; s += 2 * AD)
+            static_for<0, 2 * AD>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                if (s + u < nsteps) {
+                if (s + u < nsteps2) {
                     int nj = sj + 1, nc = sc;
                     if (nj == a.k2) { nj = 0; nc = sc + 1; }
-                    load_a(s + u + 1, fa[(u + 1) % 2]);
-                    load_b(nc < NCH ? nc : 0, nj, fb[(u + 1) % 2]);
+                    if (!(STS_RB_EXP & 2)) load_a(wrs2, s + u + AD - 1, fa[(u + AD - 1) % AD]);
+                    if (!(STS_RB_EXP & 1)) load_b(nc < NCH ? nc : 0, nj, fb[(u + 1) % 2]);
                     __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of this step's MFMAs (the scheduler would sink them)
-                    mfmas(fa[u % 2], fb[u % 2]);
+                    if (!(STS_RB_EXP & 4)) mfmas(fa[(STS_RB_EXP & 2) ? 0 : u % AD], fb[(STS_RB_EXP & 1) ? 0 : u % 2]);
                     sj = nj; sc = nc;
                 }
             });
