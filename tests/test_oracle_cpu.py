@@ -88,6 +88,37 @@ def test_port_matches_live_reference_on_realistic_weight_statistics(kind, port_b
         assert np.abs(p[k] - r[k]).max() <= TAP_MAXABS_TOL * max(1.0, float(np.abs(r[k]).max())), k
 
 
+def ms_blob_with_explicit_filter_bias(bias_value=0.0375, seed=17):
+    """A full-size MS-iSTFT blob whose learned synthesis filter (multistream_conv_post: 1 x subbands x 63, nn_conv1d.cpp:32-46) carries an
+    EXPLICIT bias: the has_bias flag of its header is set and the one bias float is written in place (the synthetic recipe only
+    emits one under stats="realistic", with whatever value the generator draws)."""
+    import dataclasses
+    cfg = dataclasses.replace(sb.full_cfg("ms_fix"), stats="realistic")
+    blob = sb.make_blob(cfg, seed).copy()
+    hdr = np.array([1, cfg.subbands, 63, 31, 1, 1], np.float32)
+    hits = [i for i in range(blob.size - 6) if blob[i] == 1.0 and np.array_equal(blob[i:i + 6], hdr)]
+    assert len(hits) == 1, hits
+    at = hits[0] + 6 + 63 * cfg.subbands
+    blob[at] = np.float32(bias_value)
+    return cfg, blob, at
+
+
+@pytest.mark.skipif(not pyref.have_ref(), reason="oracle/_ref (real reference) not built on this machine")
+def test_port_matches_live_reference_with_an_explicit_multistream_filter_bias(port_built):
+    """Full-size MS-iSTFT decoder, the synthesis filter's bias set to 0.0375 (about 1 200 LSB): restatement == compiled reference, and the
+    bias really is in the output (the same blob with the float zeroed gives a waveform lower by that amount)."""
+    cfg, blob, at = ms_blob_with_explicit_filter_bias()
+    ids = sb.synthetic_ids(9, cfg.vocab, salt=3)
+    r = pyref.RefModel(blob).infer_ids(ids, 0, 1.0, taps=True)
+    p = pyref.PortModel(blob).infer_ids(ids, 0, 1.0, taps=True)
+    assert (r["durations"] == p["durations"]).all()
+    assert_wave_close(p["wave"], r["wave"], "ms_fix, explicit filter bias")
+    assert_pcm_close(p["pcm"], r["pcm"], "ms_fix, explicit filter bias")
+    blob0 = blob.copy(); blob0[at] = 0.0
+    p0 = pyref.PortModel(blob0).infer_ids(ids, 0, 1.0)
+    assert np.abs((p["wave"] - p0["wave"]) - np.float32(0.0375)).max() <= 1e-6
+
+
 def test_port_forced_durations_and_short_inputs(port_built):
     cfg = sb.tiny_cfg("hifigan_fix")
     blob = sb.make_blob(cfg, 3)

@@ -685,6 +685,32 @@ def test_pre_split_trunk_path_matches_reference_golden(path):
     syn.close()
 
 
+def test_explicit_multistream_filter_bias_full_size():
+    """a full-size MS-iSTFT blob whose learned synthesis filter carries an explicit bias of 0.0375 (model.hip: fir_bias, added by the
+    fused iSTFT tail and by synth_fir): the HIP path against the oracle (pinned on the compiled reference by
+    tests/test_oracle_cpu.py::test_port_matches_live_reference_with_an_explicit_multistream_filter_bias), fused and unfused tail, and the bias
+    is really there.  /root/reference/src/nn_op/nn_conv1d.cpp:40-46, Generator_MS.cpp."""
+    from test_oracle_cpu import ms_blob_with_explicit_filter_bias
+    cfg, blob, at = ms_blob_with_explicit_filter_bias()
+    ids = sb.synthetic_ids(9, cfg.vocab, salt=3)
+    want = pyref.PortModel(blob).infer_ids(ids, 0, 1.0)
+    syn = engine.Synthesizer(blob)
+    syn.set_record_taps(True)
+    for fused in (1, 0):
+        syn.debug_set("tail_fused", fused)
+        syn.run_batch([ids], [0], [1.0])
+        assert_pcm_close(syn.pcm_host(), want["pcm"], f"ms_fix explicit filter bias (tail_fused={fused})")
+        assert_wave_close(syn.tap("wave")[0], want["wave"], f"ms_fix explicit filter bias (tail_fused={fused})")
+    wave = syn.tap("wave")[0].copy()
+    syn.close()
+    blob0 = blob.copy(); blob0[at] = 0.0
+    syn0 = engine.Synthesizer(blob0)
+    syn0.set_record_taps(True)
+    syn0.run_batch([ids], [0], [1.0])
+    assert np.abs((wave - syn0.tap("wave")[0]) - np.float32(0.0375)).max() <= 1e-6
+    syn0.close()
+
+
 UPS_CASES = [  # Cin, Cout, k, pad, stride, L      (HiFi-GAN: k16 s8 / k4 s2; MB-iSTFT: k16 s4; tiny models: k8 s4; odd lengths -> ragged tiles)
     (512, 256, 16, 4, 8, 668), (256, 128, 16, 4, 8, 1301), (128, 64, 4, 1, 2, 3001), (64, 32, 4, 1, 2, 4099), (256, 128, 16, 6, 4, 700),
     (64, 32, 8, 2, 4, 77), (32, 32, 16, 4, 8, 5), (96, 64, 4, 1, 2, 1), (64, 96, 11, 3, 4, 130),
