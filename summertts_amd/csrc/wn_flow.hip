@@ -48,10 +48,21 @@ __device__ __forceinline__ void split4h(const float (&x)[4], unsigned (&hi)[2], 
     for (int d = 0; d < 2; d++) {
         const f32x2 v = {x[2 * d], x[2 * d + 1]};
         const f16x2 h = __builtin_convertvector(v, f16x2);
+#if STS_SPLIT_MIX        // (conv_bf3_dev.hpp split8h: the small term as one mixed-precision FMA per value, same bits)
+        const f32x2 v2 = v * 2048.f;
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        unsigned l = 0u;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "+v"(l) : "v"(hu), "s"(-2048.0f), "v"(v2[0]), "v"(v2[1]));
+        hi[d] = hu;
+        lo[d] = l;
+#else
         const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * 2048.f;
         const f16x2 l = __builtin_convertvector(r, f16x2);
         hi[d] = __builtin_bit_cast(unsigned, h);
         lo[d] = __builtin_bit_cast(unsigned, l);
+#endif
         amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
     }
 }
